@@ -1,0 +1,148 @@
+"""Configuration for the MI355X-native HumanNeRF hot path.
+
+The reference keeps a process-global yacs singleton ``cfg`` that every module
+imports (reference: configs/config.py:58-80, configs/default.yaml).  The hot
+path reads only a handful of its keys *at call time* (SURVEY.md section 5):
+``N_samples, perturb, chunk, netchunk_per_gpu, ignore_non_rigid_motions,
+total_bones, *.kick_in_iter / full_band_iter`` plus the MLP shapes.
+
+Drop-in rule: when this package is loaded inside the reference tree (its
+``configs`` package was already imported by train.py / run.py) we use THAT
+object, so late mutations such as ``cfg.perturb = 0.`` made by the reference's
+drivers (run.py:71,215; trainer.py:181,265) are honoured.  Stand-alone we use
+the defaults below, which restate the default.yaml values the path depends on.
+"""
+import copy
+import sys
+
+import yaml
+
+
+class CfgNode(dict):
+    """Minimal attribute-dict config node (own implementation, not yacs)."""
+
+    def __init__(self, init=None):
+        super().__init__()
+        for k, v in (init or {}).items():
+            self[k] = CfgNode(v) if isinstance(v, dict) else v
+
+    def __getattr__(self, name):
+        try:
+            return self[name]
+        except KeyError:
+            raise AttributeError(name)
+
+    def __setattr__(self, name, value):
+        self[name] = CfgNode(value) if isinstance(value, dict) and not isinstance(value, CfgNode) else value
+
+    def clone(self):
+        return copy.deepcopy(self)
+
+    def merge(self, other):
+        for k, v in other.items():
+            if isinstance(v, dict) and isinstance(self.get(k), dict):
+                self[k].merge(v)
+            else:
+                self[k] = CfgNode(v) if isinstance(v, dict) else v
+        return self
+
+    def merge_from_file(self, path):
+        with open(path, 'r') as f:
+            return self.merge(yaml.safe_load(f) or {})
+
+    def merge_from_list(self, opts):
+        """``['a.b', '3', 'c', 'x']`` pairs, values parsed as YAML scalars
+        (same convention as the reference CLI, configs/config.py:63)."""
+        assert len(opts) % 2 == 0, opts
+        for key, val in zip(opts[0::2], opts[1::2]):
+            node = self
+            parts = key.split('.')
+            for p in parts[:-1]:
+                node = node[p]
+            if parts[-1] not in node:
+                raise KeyError(f'unknown config key {key}')
+            node[parts[-1]] = yaml.safe_load(val) if isinstance(val, str) else val
+        return self
+
+
+# Values restate configs/default.yaml of the reference (line numbers cited).
+_DEFAULTS = {
+    'category': 'human_nerf',
+    'random_seed': 42,
+    'use_amp': False,
+    'eval_iter': 10000000,                     # config.py:16
+    'ignore_non_rigid_motions': False,         # config.py:20
+    'network_module': 'humannerf_amd.network',
+    'canonical_mlp': {                         # default.yaml:51-57
+        'mlp_depth': 8, 'mlp_width': 256, 'multires': 10, 'i_embed': 0,
+        'view_dir': False, 'pose_color': 'wo', 'last_linear_scale': 1,
+    },
+    'mweight_volume': {                        # default.yaml:133-137
+        'embedding_size': 256, 'volume_size': 32, 'dst_voxel_size': 0.0625,
+    },
+    'posevec': {'type': 'axis_angle'},
+    'non_rigid_motion_model': 'mlp',
+    'non_rigid_motion_mlp': {                  # default.yaml:142-165
+        'condition_code_size': 69, 'pose_input': True, 'time_input': False,
+        'mlp_width': 128, 'mlp_depth': 6, 'skips': [4], 'multires': 6,
+        'i_embed': 0, 'kick_in_iter': 10000, 'full_band_iter': 50000,
+        'last_linear_scale': 1,
+    },
+    'pose_decoder': {                          # default.yaml:237-242
+        'embedding_size': 69, 'mlp_width': 256, 'mlp_depth': 4,
+    },
+    'pose_decoder_off': False,
+    'train': {                                 # default.yaml:261-281
+        'perturb': 1.0, 'batch_size': 1, 'shuffle': True, 'drop_last': False,
+        'maxiter': 400000, 'lr': 0.0005, 'lr_mweight_vol_decoder': 0.00005,
+        'lr_pose_decoder': 0.00005, 'lr_non_rigid_mlp': 0.00005,
+        'lrate_decay': 500, 'optimizer': 'adam', 'log_interval': 20,
+        'save_checkpt_interval': 2000, 'save_model_interval': 50000,
+        'ray_shoot_mode': 'patch', 'selected_frame': 'all',
+        'lossweights': {'lpips': 1.0, 'mse': 0.2, 'l1': 0.0},
+    },
+    'sex': 'neutral',
+    'total_bones': 24,                         # default.yaml:346
+    'bbox_offset': 0.3,                        # default.yaml:347
+    'bgcolor': [0., 0., 0.],
+    'patch': {'sample_subject_ratio': 0.8, 'N_patches': 6, 'size': 32},
+    'N_samples': 128,                          # default.yaml:357
+    'perturb': 1.0,                            # default.yaml:359
+    'netchunk_per_gpu': 300000,                # default.yaml:361
+    'chunk': 32768,                            # default.yaml:362
+    'n_gpus': 1,
+    # --- keys that exist only in this build -------------------------------
+    'amd': {
+        # arithmetic of the two per-sample MLPs: 'f32' = v_mfma_f32_32x32x2_f32
+        # (bitwise an fp32 fma chain); 'f16x3' = split-fp16 3-MFMA emulation.
+        'mlp_mode': 'f32',
+        # materialise the per-sample diagnostic outputs the reference always
+        # returns (backward_motion_weights, xyz_on_rays, ...; ~17 KB/ray).
+        'diagnostics': True,
+        # cache the motion-weight volume across eval-mode frames while the
+        # decoder parameters and the priors tensor are unchanged.
+        'cache_weight_volume': True,
+    },
+}
+
+
+def get_cfg_defaults():
+    return CfgNode(_DEFAULTS)
+
+
+def _resolve_cfg():
+    ref = sys.modules.get('configs')
+    if ref is not None and hasattr(ref, 'cfg'):
+        return ref.cfg           # reference singleton: drop-in mode
+    return get_cfg_defaults()
+
+
+cfg = _resolve_cfg()
+
+
+def amd_option(name, default=None):
+    """Read a build-specific option; the reference cfg has no ``amd`` node."""
+    node = cfg.get('amd', None) if hasattr(cfg, 'get') else None
+    if node is None:
+        return _DEFAULTS['amd'].get(name, default)
+    return node.get(name, _DEFAULTS['amd'].get(name, default))

@@ -1,0 +1,241 @@
+"""Per-frame inputs of the renderer: skeleton kinematics, weight-volume priors,
+camera rays and ray/bbox intersection (host side, numpy).
+
+These are the producers of the dict consumed by ``Network.forward`` -- the
+"next" row of SURVEY.md section 8(f) rank 1.  Each function states the reference
+routine whose *result* it reproduces; the code is vectorised and written for
+this repo (no per-bone python loops over voxels, no cv2).
+
+Also provides ``synthetic_frame`` -- the synthetic T-pose-skeleton scene of
+SURVEY.md Appendix A.2 used by bench.py, smoke() and the golden fixtures (no
+dataset, SMPL model or checkpoint is available offline).
+"""
+import numpy as np
+
+# SMPL kinematic tree (reference: core/utils/body_util.py:32-35).
+SMPL_PARENT = np.array([-1, 0, 0, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 9, 9, 12, 13,
+                        14, 16, 17, 18, 19, 20, 21], dtype=np.int64)
+TORSO_JOINTS = (0, 3, 6, 9, 13, 14)        # body_util.py:37-42
+HEAD_JOINT = 15
+BONE_STDS = np.array([0.03, 0.06, 0.03])   # body_util.py:43-45
+HEAD_STDS = np.array([0.06, 0.06, 0.06])
+JOINT_STDS = np.array([0.02, 0.02, 0.02])
+
+# Synthetic 24-joint T-pose (metres), SURVEY.md Appendix A.2.
+TPOSE_JOINTS = np.array([
+    [0.00, 0.00, 0.00], [0.07, -0.09, 0.00], [-0.07, -0.09, 0.00],
+    [0.00, 0.11, -0.02], [0.10, -0.47, 0.00], [-0.10, -0.47, 0.00],
+    [0.00, 0.25, 0.00], [0.09, -0.87, -0.03], [-0.09, -0.87, -0.03],
+    [0.00, 0.30, 0.02], [0.11, -0.93, 0.09], [-0.11, -0.93, 0.09],
+    [0.00, 0.51, -0.01], [0.08, 0.42, 0.00], [-0.08, 0.42, 0.00],
+    [0.00, 0.60, 0.03], [0.18, 0.44, 0.00], [-0.18, 0.44, 0.00],
+    [0.43, 0.44, -0.01], [-0.43, 0.44, -0.01], [0.68, 0.44, 0.00],
+    [-0.68, 0.44, 0.00], [0.77, 0.43, 0.00], [-0.77, 0.43, 0.00],
+], dtype=np.float32)
+
+
+def _skew(v):
+    x, y, z = v
+    return np.array([[0, -z, y], [z, 0, -x], [-y, x, 0]], dtype=np.float64)
+
+
+def rodrigues(rvec):
+    """Axis-angle -> 3x3, with the reference's ``norm + 1e-5`` axis
+    normalisation (body_util.py:200-219)."""
+    rvec = np.asarray(rvec, dtype=np.float64).reshape(3)
+    theta = np.linalg.norm(rvec)
+    r = rvec / (theta + 1e-5)
+    return (np.cos(theta) * np.eye(3) + np.sin(theta) * _skew(r)
+            + (1.0 - np.cos(theta)) * np.outer(r, r))
+
+
+def body_pose_to_body_RTs(jangles, tpose_joints):
+    """Local joint rotations / parent-relative offsets.
+    Result of body_util.py:222-248: Rs (J,3,3) f32, Ts (J,3) f32."""
+    jangles = np.asarray(jangles).reshape(-1, 3)
+    J = jangles.shape[0]
+    Rs = np.stack([rodrigues(jangles[i]) for i in range(J)]).astype(np.float32)
+    Ts = tpose_joints.astype(np.float32).copy()
+    Ts[1:] = tpose_joints[1:] - tpose_joints[SMPL_PARENT[1:]]
+    return Rs, Ts
+
+
+def get_canonical_global_tfms(canonical_joints):
+    """Global 4x4 transforms of the rest pose: pure translations accumulated
+    down the tree (body_util.py:251-271)."""
+    J = canonical_joints.shape[0]
+    g = np.zeros((J, 4, 4), dtype=np.float32)
+    g[:, 3, 3] = 1.0
+    g[:, :3, :3] = np.eye(3, dtype=np.float32)
+    local = canonical_joints.astype(np.float32).copy()
+    local[1:] = canonical_joints[1:] - canonical_joints[SMPL_PARENT[1:]]
+    for i in range(J):
+        # float32 products of [I|t] matrices, parent first (same association).
+        loc = np.eye(4, dtype=np.float32)
+        loc[:3, 3] = local[i]
+        g[i] = loc if i == 0 else g[SMPL_PARENT[i]].dot(loc)
+    return g
+
+
+def _align_y_to(direction):
+    """Rotation taking +y onto ``direction`` (body_util.py:83-116)."""
+    v1 = np.array([0.0, 1.0, 0.0], dtype=np.float32)
+    v2 = direction.astype(np.float32)
+    v1 = v1 / np.clip(np.linalg.norm(v1), 1e-5, None)
+    v2 = v2 / np.clip(np.linalg.norm(v2), 1e-5, None)
+    n = np.cross(v1, v2)
+    c = float(v1.dot(v2))
+    K = _skew(n).astype(np.float32)
+    return (np.eye(3) + K + K.dot(K) * (1.0 / (1.0 + c))).astype(np.float32)
+
+
+def _gaussian_volume(grid_xyz, center, inv_std, rot):
+    """exp(-d^T R S S R^T d) on the grid (body_util.py:136-178)."""
+    S = np.diag(inv_std.astype(np.float32))
+    sigma = rot.dot(S).dot(S).dot(rot.T)
+    d = grid_xyz - np.asarray(center)
+    q = np.einsum('...i,ij,...j->...', d, sigma, d)
+    return np.exp(-q)
+
+
+def approx_gaussian_bone_volumes(tpose_joints, bbox_min_xyz, bbox_max_xyz,
+                                 grid_size=32):
+    """Priors for the motion-weight volume: (J+1, G, G, G), background last,
+    indexed [z][y][x] (body_util.py:274-348)."""
+    tpose_joints = tpose_joints.astype(np.float32)
+    J = tpose_joints.shape[0]
+    ax = [np.linspace(bbox_min_xyz[i], bbox_max_xyz[i], grid_size) for i in range(3)]
+    zg, yg, xg = np.meshgrid(ax[2], ax[1], ax[0], indexing='ij')
+    grid = np.stack([xg, yg, zg], axis=-1)
+
+    vols = []
+    for j in range(J):
+        children = np.nonzero(SMPL_PARENT == j)[0]
+        if len(children) > 0:
+            vol = np.zeros((grid_size,) * 3, dtype=np.float32)
+            for c in children:
+                inv_std = 1.0 / (BONE_STDS * 2.0)
+                inv_std = inv_std.astype(np.float32)
+                if j in TORSO_JOINTS:
+                    inv_std[0] *= 1 / 1.5
+                    inv_std[2] *= 1 / 1.5
+                start, end = tpose_joints[j], tpose_joints[c]
+                rot = _align_y_to(end - start)
+                vol = vol + _gaussian_volume(grid, (start + end) / 2.0, inv_std, rot)
+        else:
+            stds = HEAD_STDS if j == HEAD_JOINT else JOINT_STDS
+            inv_std = (1.0 / (stds * 2.0)).astype(np.float32)
+            vol = _gaussian_volume(grid, tpose_joints[j], inv_std,
+                                   np.eye(3, dtype=np.float32))
+        vols.append(vol)
+    vols = np.stack(vols, axis=0)
+    bg = 1.0 - np.sum(vols, axis=0, keepdims=True).clip(min=0.0, max=1.0)
+    vols = np.concatenate([vols, bg], axis=0)
+    return vols / np.sum(vols, axis=0, keepdims=True).clip(min=0.001)
+
+
+def get_camrot(campos, lookat=None, inv_camera=False):
+    """Rows = right, up, forward (camera_util.py:50-79)."""
+    lookat = np.zeros(3, dtype=np.float32) if lookat is None else np.asarray(lookat)
+    up = np.array([0.0, -1.0 if inv_camera else 1.0, 0.0], dtype=np.float32)
+    fwd = lookat - campos
+    fwd = fwd / np.linalg.norm(fwd)
+    right = np.cross(up, fwd)
+    right = right / np.linalg.norm(right)
+    up = np.cross(fwd, right)
+    up = up / np.linalg.norm(up)
+    return np.array([right, up, fwd], dtype=np.float32)
+
+
+def get_rays_from_KRT(H, W, K, R, T):
+    """Pixel rays in world space, direction NOT normalised
+    (camera_util.py:132-159)."""
+    rays_o = -np.dot(R.T, T).ravel()
+    i, j = np.meshgrid(np.arange(W, dtype=np.float32),
+                       np.arange(H, dtype=np.float32), indexing='xy')
+    xy1 = np.stack([i, j, np.ones_like(i)], axis=2)
+    pix_cam = np.dot(xy1, np.linalg.inv(K).T)
+    pix_world = np.dot(pix_cam - T.ravel(), R)
+    rays_d = pix_world - rays_o[None, None]
+    return np.broadcast_to(rays_o, rays_d.shape), rays_d
+
+
+def rays_intersect_3d_bbox(bounds, ray_o, ray_d):
+    """Slab test against the bbox padded by 1 cm; keeps rays that hit exactly
+    two faces.  Returns near, far (valid rays only) and the hit mask
+    (camera_util.py:162-208).  ``ray_d`` is clamped in place like the
+    reference does."""
+    if isinstance(bounds, dict):
+        bounds = np.stack([bounds['min_xyz'], bounds['max_xyz']], axis=0)
+    assert bounds.shape == (2, 3)
+    bounds = bounds + np.array([-0.01, 0.01])[:, None]
+    ray_d[np.abs(ray_d) < 1e-5] = 1e-5
+    t = ((bounds[None] - ray_o[:, None]) / ray_d[:, None]).reshape(-1, 6)
+    p = t[..., None] * ray_d[:, None] + ray_o[:, None]
+    lo, hi = bounds[0] - 1e-6, bounds[1] + 1e-6
+    inside = np.all((p >= lo) & (p <= hi), axis=-1)
+    hit = inside.sum(-1) == 2
+    pts = p[hit][inside[hit]].reshape(-1, 2, 3)
+    o, d = ray_o[hit], ray_d[hit]
+    nrm = np.linalg.norm(d, axis=1)
+    d0 = np.linalg.norm(pts[:, 0] - o, axis=1) / nrm
+    d1 = np.linalg.norm(pts[:, 1] - o, axis=1) / nrm
+    return np.minimum(d0, d1), np.maximum(d0, d1), hit
+
+
+def tpose_camera(img_size, radius=6.0, focal=1250.0):
+    """Orbit camera of the reference's T-pose renderer
+    (core/data/human_nerf/tpose.py:65-84)."""
+    campos = np.array([0.0, -0.25, radius], dtype=np.float32)
+    camrot = get_camrot(campos, lookat=np.array([0, -0.25, 0.0]), inv_camera=True)
+    E = np.eye(4, dtype=np.float32)
+    E[:3, :3] = camrot
+    E[:3, 3] = -camrot.dot(campos)
+    K = np.eye(3, dtype=np.float32)
+    K[0, 0] = K[1, 1] = focal
+    K[:2, 2] = img_size / 2.0
+    return K, E
+
+
+def synthetic_frame(H=512, W=512, pose_seed=0, pose_scale=0.2, focal_at_512=1700.0,
+                    bbox_offset=0.3, volume_size=32, bgcolor=(0.0, 0.0, 0.0),
+                    ray_stride=1):
+    """The synthetic frame of SURVEY.md Appendix A.2 / section 8(d).
+
+    Returns the numpy dict a reference dataset would yield for one frame
+    (keys as consumed by Network.forward).  ``focal_at_512=1700`` makes every
+    pixel ray hit the canonical bbox so that R == H*W exactly; 1250 is the
+    T-pose renderer's framing (about 88 % of the pixels hit).
+    ``ray_stride`` sub-samples the pixel grid (golden fixtures use few rays).
+    """
+    J = TPOSE_JOINTS
+    mn, mx = J.min(0) - bbox_offset, J.max(0) + bbox_offset
+    priors = approx_gaussian_bone_volumes(J, mn, mx, volume_size).astype(np.float32)
+    poses = np.random.RandomState(pose_seed).randn(72) * pose_scale
+    poses[:3] = 0.0
+    dst_Rs, dst_Ts = body_pose_to_body_RTs(poses, J)
+    cnl_gtfms = get_canonical_global_tfms(J)
+    dst_posevec = (poses[3:] + 1e-2).astype(np.float32)
+
+    K, E = tpose_camera(np.array([W, H], dtype=np.float32), 6.0,
+                        focal_at_512 * H / 512.0)
+    rays_o, rays_d = get_rays_from_KRT(H, W, K, E[:3, :3], E[:3, 3])
+    rays_o = rays_o[::ray_stride, ::ray_stride].reshape(-1, 3).astype(np.float32)
+    rays_d = rays_d[::ray_stride, ::ray_stride].reshape(-1, 3).astype(np.float32)
+    rays_d = rays_d.copy()
+    near, far, hit = rays_intersect_3d_bbox(np.stack([mn, mx]), rays_o, rays_d)
+    rays_o, rays_d = rays_o[hit], rays_d[hit]
+    return {
+        'rays': np.stack([rays_o, rays_d, rays_d], axis=0).astype(np.float32),
+        'near': near[:, None].astype(np.float32),
+        'far': far[:, None].astype(np.float32),
+        'ray_mask': hit,
+        'dst_Rs': dst_Rs, 'dst_Ts': dst_Ts, 'cnl_gtfms': cnl_gtfms,
+        'motion_weights_priors': priors,
+        'dst_posevec': dst_posevec,
+        'cnl_bbox_min_xyz': mn.astype(np.float32),
+        'cnl_bbox_max_xyz': mx.astype(np.float32),
+        'cnl_bbox_scale_xyz': (2.0 / (mx - mn)).astype(np.float32),
+        'bgcolor': np.array(bgcolor, dtype=np.float32),
+        'img_width': W, 'img_height': H,
+    }

@@ -1,0 +1,188 @@
+"""Generate the golden fixtures under tests/golden/ by running the REFERENCE
+(imported read-only from /root/reference, CPU) on seeded weights and the
+synthetic frame of humannerf_amd/scene.py.
+
+Run in the build container only (the reference does not exist on the GPU box):
+
+    python oracle/make_golden.py            # writes tests/golden/*.npz + meta.json
+
+Harness recipe: SURVEY.md section 8(c).  Nothing from the reference is copied; only
+its numerical outputs are stored.  Also cross-checks this repo's numpy scene
+helpers against the reference's own helpers, and records the reference's CPU
+rays/s (indicative baseline).
+"""
+import json
+import os
+import sys
+import time
+import types
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = '/root/reference'
+GOLD = os.path.join(REPO, 'tests', 'golden')
+
+ORACLE_YAML = """\
+task: 'zju_mocap'
+subject: 'p387'
+experiment: 'oracle_cpu'
+primary_gpus: ['cpu']
+secondary_gpus: ['cpu']
+bgcolor: [0., 0., 0.]
+resize_img_scale: 0.5
+"""
+
+
+def import_reference():
+    sys.dont_write_bytecode = True
+    os.makedirs('/tmp/hnrf_oracle', exist_ok=True)
+    ypath = '/tmp/hnrf_oracle/oracle.yaml'
+    with open(ypath, 'w') as f:
+        f.write(ORACLE_YAML)
+    os.chdir(REF)
+    sys.path.insert(0, REF)
+    sys.path.insert(1, REPO)
+    sys.argv = ['make_golden', '--cfg', ypath]
+    for name in ['cv2', 'torchvision', 'torchvision.models', 'torchvision.transforms']:
+        sys.modules[name] = types.ModuleType(name)
+    sys.modules['torchvision'].models = sys.modules['torchvision.models']
+    sys.modules['torchvision'].transforms = sys.modules['torchvision.transforms']
+    sys.modules['torchvision.transforms'].Compose = lambda *a, **k: None
+    sys.modules['torchvision.transforms'].Normalize = lambda *a, **k: None
+    from configs import cfg
+    from core.nets import create_network
+    return cfg, create_network
+
+
+def main():
+    import numpy as np
+    import torch
+    torch.set_num_threads(8)
+    cfg, create_network = import_reference()
+    from humannerf_amd import scene
+    from oracle.seeded import seeded_state
+
+    # ---- cross-check the scene helpers against the reference's numpy helpers
+    from core.utils import body_util as rb, camera_util as rc
+    J = scene.TPOSE_JOINTS
+    mn, mx = J.min(0) - 0.3, J.max(0) + 0.3
+    poses = np.random.RandomState(0).randn(72) * 0.2
+    poses[:3] = 0
+    a = rb.body_pose_to_body_RTs(poses, J)
+    b = scene.body_pose_to_body_RTs(poses, J)
+    assert np.allclose(a[0], b[0], atol=1e-6) and np.allclose(a[1], b[1], atol=0)
+    assert np.allclose(rb.get_canonical_global_tfms(J), scene.get_canonical_global_tfms(J), atol=1e-7)
+    pa = rb.approx_gaussian_bone_volumes(J, mn, mx, 32)
+    pb = scene.approx_gaussian_bone_volumes(J, mn, mx, 32)
+    print('priors max|diff|', np.abs(pa - pb).max())
+    assert np.allclose(pa, pb, atol=2e-6)
+    K, E = scene.tpose_camera(np.array([64., 64.], dtype=np.float32), 6.0, 1250 * 64 / 512)
+    ro, rd = rc.get_rays_from_KRT(64, 64, K, E[:3, :3], E[:3, 3])
+    so, sd = scene.get_rays_from_KRT(64, 64, K, E[:3, :3], E[:3, 3])
+    assert np.array_equal(ro, so) and np.array_equal(rd, sd)
+    n1 = rc.rays_intersect_3d_bbox(np.stack([mn, mx]), ro.reshape(-1, 3).copy(), rd.reshape(-1, 3).copy())
+    n2 = scene.rays_intersect_3d_bbox(np.stack([mn, mx]), so.reshape(-1, 3).copy(), sd.reshape(-1, 3).copy())
+    assert all(np.array_equal(x, y) for x, y in zip(n1, n2))
+    assert np.allclose(rc.get_camrot(np.array([0, -.25, 6.], dtype=np.float32), np.array([0, -.25, 0.]), True),
+                       scene.get_camrot(np.array([0, -.25, 6.], dtype=np.float32), np.array([0, -.25, 0.]), True))
+    print('scene helpers agree with the reference helpers')
+
+    # ---- reference network with seeded parameters
+    net = create_network()
+    shapes = {k: tuple(v.shape) for k, v in net.state_dict().items()}
+    state = seeded_state(shapes, seed=0)
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in state.items()}, strict=True)
+    net.eval()
+    Net = type(net)
+
+    captured = {}
+    orig_smf = Net._sample_motion_fields
+    orig_r2o = Net._raw2outputs
+
+    def smf(**kw):
+        r = orig_smf(**kw)
+        captured.setdefault('x_skel', []).append(r['x_skel'].detach())
+        captured.setdefault('mask', []).append(r['fg_likelihood_mask'].detach()[..., 0])
+        return r
+
+    def r2o(raw, raw_mask, z_vals, rays_d, xyz, bgcolor=None):
+        captured.setdefault('raw', []).append(raw.detach())
+        captured.setdefault('z_vals', []).append(z_vals.detach())
+        return orig_r2o(raw, raw_mask, z_vals, rays_d, xyz, bgcolor)
+
+    Net._sample_motion_fields = staticmethod(smf)
+    Net._raw2outputs = staticmethod(r2o)
+
+    def frame_tensors(fr):
+        keys = ['rays', 'near', 'far', 'dst_Rs', 'dst_Ts', 'cnl_gtfms', 'motion_weights_priors',
+                'dst_posevec', 'cnl_bbox_min_xyz', 'cnl_bbox_scale_xyz', 'bgcolor']
+        d = {k: torch.from_numpy(np.ascontiguousarray(fr[k])) for k in keys}
+        d['head_id'] = torch.tensor(-1)
+        return d
+
+    def run_case(name, fr, iter_val, S, perturb=0.0, ignore_nr=False, t_rand=None, keep_rays=24):
+        cfg.N_samples = S
+        cfg.perturb = perturb
+        cfg.ignore_non_rigid_motions = ignore_nr
+        captured.clear()
+        real_rand = torch.rand
+        if t_rand is not None:
+            torch.rand = lambda *a, **k: torch.from_numpy(t_rand)
+        try:
+            with torch.no_grad():
+                out = net(**frame_tensors(fr), iter_val=iter_val)
+        finally:
+            torch.rand = real_rand
+        save = {}
+        per_sample = ('weights_on_rays', 'xyz_on_rays', 'rgb_on_rays', 'backward_motion_weights', 'offsets')
+        for k, v in out.items():
+            v = v.numpy()
+            save[k] = v[:keep_rays] if k in per_sample else v
+        for k, v in captured.items():
+            save['_' + k] = torch.cat(v, 0).numpy()[:keep_rays]
+        if t_rand is not None:
+            save['t_rand'] = t_rand
+        save['_vol_slice'] = net.motion_weights_vol.detach().numpy()[:, 12:20:3, 8:24:5, 8:24:5]
+        meta = dict(iter_val=float(iter_val), N_samples=S, perturb=perturb, ignore_non_rigid_motions=ignore_nr,
+                    n_rays=int(out['rgb'].shape[0]), keep_rays=keep_rays)
+        np.savez_compressed(os.path.join(GOLD, name + '.npz'), **save)
+        st = {k: (float(np.abs(v).mean()), float(np.abs(v).max())) for k, v in save.items() if k in
+              ('rgb', 'alpha', 'depth', 'offsets')}
+        print(name, meta, st)
+        return meta
+
+    os.makedirs(GOLD, exist_ok=True)
+    fr = scene.synthetic_frame(H=512, W=512, focal_at_512=1250.0, ray_stride=41)
+    print('rays in golden frame:', fr['rays'].shape)
+    metas = {'frame': dict(H=512, W=512, focal_at_512=1250.0, ray_stride=41, pose_seed=0, seed=0)}
+    metas['eval_s128'] = run_case('eval_s128', fr, 1e7, 128)
+    metas['eval_s64'] = run_case('eval_s64', fr, 1e7, 64)
+    metas['tpose_s128'] = run_case('tpose_s128', fr, 1e7, 128, ignore_nr=True)
+    metas['iter0_s128'] = run_case('iter0_s128', fr, 0.0, 128)
+    metas['iter5000_s128'] = run_case('iter5000_s128', fr, 5000.0, 128)
+    metas['iter30000_s128'] = run_case('iter30000_s128', fr, 30000.0, 128)
+    R = fr['rays'].shape[1]
+    t_rand = np.random.RandomState(7).rand(R, 128).astype(np.float32)
+    metas['perturb_s128'] = run_case('perturb_s128', fr, 1e7, 128, perturb=1.0, t_rand=t_rand)
+
+    # ---- reference CPU throughput (indicative)
+    cfg.N_samples, cfg.perturb, cfg.ignore_non_rigid_motions = 128, 0.0, False
+    frb = scene.synthetic_frame(H=512, W=512, focal_at_512=1700.0, ray_stride=4)   # 128x128 rays of C2
+    tens = frame_tensors(frb)
+    times = []
+    with torch.no_grad():
+        net(**tens, iter_val=1e7)
+        for _ in range(3):
+            t0 = time.time()
+            net(**tens, iter_val=1e7)
+            times.append(time.time() - t0)
+    nr = frb['rays'].shape[1]
+    metas['reference_cpu'] = dict(rays=nr, samples=128, seconds_median=float(np.median(times)),
+                                  rays_per_s=float(nr / np.median(times)), threads=torch.get_num_threads(),
+                                  torch=torch.__version__, note='reference Network.forward, eval, perturb=0')
+    print(metas['reference_cpu'])
+    with open(os.path.join(GOLD, 'meta.json'), 'w') as f:
+        json.dump(metas, f, indent=1)
+
+
+if __name__ == '__main__':
+    main()
