@@ -1,0 +1,59 @@
+"""ctypes binding of libhnrf.so (the C ABI declared in include/hnrf.h).
+
+The library is built in-tree by ``__graft_entry__.build()`` /
+``make -C humannerf_amd/csrc``.  There is NO fallback: if the shared object is
+missing or a symbol cannot be resolved, importing/using the ops raises.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libhnrf.so')
+
+_vp, _i64, _int, _sz = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_size_t
+
+# name -> (restype, argtypes); mirrors include/hnrf.h one to one
+SIGNATURES = {
+    'hnrf_abi_version': (_int, []),
+    'hnrf_last_error': (ctypes.c_char_p, []),
+    'hnrf_sample_warp_fwd': (_int, [_vp] * 10 + [_i64, _int, _int, _int] + [_vp] * 4 + [_vp]),
+    'hnrf_nonrigid_packed_bytes': (_sz, [_int]),
+    'hnrf_nonrigid_pack': (_int, [_vp, _vp, _vp, _int, _vp, _vp]),
+    'hnrf_nonrigid_fwd': (_int, [_vp, _vp, _vp, _int, _i64, _vp, _vp, _vp]),
+    'hnrf_canonical_packed_bytes': (_sz, [_int]),
+    'hnrf_canonical_pack': (_int, [_vp, _vp, _int, _vp, _vp]),
+    'hnrf_canonical_fwd': (_int, [_vp, _vp, _int, _i64, _vp, _vp]),
+    'hnrf_composite_fwd': (_int, [_vp] * 6 + [_i64, _int] + [_vp] * 8 + [_vp]),
+    'hnrf_render_workspace_bytes': (_sz, [_i64, _int]),
+    'hnrf_render_rays_fwd': (_int, [_vp] * 14 + [_int, _i64, _int, _int, _int, _vp, _sz, _vp, _vp, _vp, _vp]),
+}
+
+_lib = None
+
+
+class HnrfError(RuntimeError):
+    pass
+
+
+def load():
+    """Load libhnrf.so and type every exported entry point.  Fails loudly."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.isfile(LIB_PATH):
+        raise HnrfError(
+            f'{LIB_PATH} not found: build it with `python -c "import __graft_entry__ as g; g.build()"` '
+            f'or `make -C humannerf_amd/csrc`. There is no CPU/PyTorch fallback for the hot path.')
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if a declared symbol is missing
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = load().hnrf_last_error()
+        raise HnrfError(f'{what} failed ({rc}): {msg.decode() if msg else "?"}')

@@ -1,0 +1,141 @@
+// K1: z-sampling along the ray + inverse-LBS warp into the canonical space.
+//
+// One lane per sample.  For each of the B bones: bone-local position
+// pos = R_b x + T_b, trilinear lookup of the bone's 32^3 skinning-weight channel
+// at pos (align_corners, zero padding -- the F.grid_sample semantics of the
+// reference, network.py:409-413), then x_skel = sum_b w_b pos_b / max(sum w, 1e-4).
+// The reference computes the 24 bone-local positions twice and launches 24
+// grid_sample kernels (network.py:407-425); here everything stays in registers.
+//
+// Memory: the weight volume (24 x 32^3 fp32 = 3.1 MB) is L2-resident; the 8
+// corner gathers per bone are the dominant traffic (768 B of cache traffic per
+// sample).  HBM traffic per sample is 4 B (z) + 12 B (x_skel) + 4 B (mask) out.
+#include "hnrf_common.h"
+
+namespace hnrf {
+
+// torch.linspace(0, 1, S)[s] in fp32 (start + step*i below the midpoint,
+// end - step*(S-1-i) above it), then the reference's lerp (network.py:457-458).
+__device__ __forceinline__ float z_at(float nr, float fr, int s, int S) {
+    const float step = 1.0f / (float)(S - 1);
+    const float t = (s < S / 2) ? step * (float)s : 1.0f - step * (float)(S - 1 - s);
+    return nr * (1.0f - t) + fr * t;
+}
+
+template <bool WRITE_BMW>
+__global__ __launch_bounds__(256) void sample_warp_kernel(
+    const float* __restrict__ rays_o, const float* __restrict__ rays_d,
+    const float* __restrict__ near, const float* __restrict__ far,
+    const float* __restrict__ t_rand,
+    const float* __restrict__ Rs, const float* __restrict__ Ts,
+    const float* __restrict__ vol, const float* __restrict__ bbox_min,
+    const float* __restrict__ bbox_scale,
+    int64_t P, int S, int B, int G,
+    float* __restrict__ z_vals, float* __restrict__ x_skel,
+    float* __restrict__ fg_mask, float* __restrict__ bmw) {
+    const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (p >= P) return;
+    const int64_t r = p / S;
+    const int s = (int)(p - r * S);
+
+    const float nr = near[r], fr = far[r];
+    float z = z_at(nr, fr, s, S);
+    if (t_rand != nullptr) {   // _stratified_sampling, network.py:463-471
+        const float zm = (s > 0) ? z_at(nr, fr, s - 1, S) : z;
+        const float zp = (s < S - 1) ? z_at(nr, fr, s + 1, S) : z;
+        const float lower = (s > 0) ? 0.5f * (z + zm) : z;
+        const float upper = (s < S - 1) ? 0.5f * (zp + z) : z;
+        z = lower + (upper - lower) * t_rand[p];
+    }
+    const float px = rays_o[r * 3 + 0] + rays_d[r * 3 + 0] * z;
+    const float py = rays_o[r * 3 + 1] + rays_d[r * 3 + 1] * z;
+    const float pz = rays_o[r * 3 + 2] + rays_d[r * 3 + 2] * z;
+
+    const float bmx = bbox_min[0], bmy = bbox_min[1], bmz = bbox_min[2];
+    const float bsx = bbox_scale[0], bsy = bbox_scale[1], bsz = bbox_scale[2];
+    const float gm1 = (float)(G - 1);
+    const int GG = G * G;
+
+    float wsum = 0.f, ax = 0.f, ay = 0.f, az = 0.f;
+#pragma unroll 4
+    for (int b = 0; b < B; ++b) {
+        const float* Rb = Rs + b * 9;   // wave-uniform address: scalar loads
+        const float* Tb = Ts + b * 3;
+        const float qx = Rb[0] * px + Rb[1] * py + Rb[2] * pz + Tb[0];
+        const float qy = Rb[3] * px + Rb[4] * py + Rb[5] * pz + Tb[1];
+        const float qz = Rb[6] * px + Rb[7] * py + Rb[8] * pz + Tb[2];
+        // normalised grid coordinate, then grid_sample's align_corners un-normalise
+        const float ix = (((qx - bmx) * bsx - 1.0f) + 1.0f) * 0.5f * gm1;
+        const float iy = (((qy - bmy) * bsy - 1.0f) + 1.0f) * 0.5f * gm1;
+        const float iz = (((qz - bmz) * bsz - 1.0f) + 1.0f) * 0.5f * gm1;
+        const float fx0 = floorf(ix), fy0 = floorf(iy), fz0 = floorf(iz);
+        const float wx1 = ix - fx0, wy1 = iy - fy0, wz1 = iz - fz0;
+        const float wx0 = (fx0 + 1.0f) - ix, wy0 = (fy0 + 1.0f) - iy, wz0 = (fz0 + 1.0f) - iz;
+        // clamp before the int conversion: far-away points must not overflow
+        const int x0 = (int)fminf(fmaxf(fx0, -2.0f), gm1 + 1.0f);
+        const int y0 = (int)fminf(fmaxf(fy0, -2.0f), gm1 + 1.0f);
+        const int z0 = (int)fminf(fmaxf(fz0, -2.0f), gm1 + 1.0f);
+        const bool vx0 = (x0 >= 0) & (x0 < G), vx1 = (x0 + 1 >= 0) & (x0 + 1 < G);
+        const bool vy0 = (y0 >= 0) & (y0 < G), vy1 = (y0 + 1 >= 0) & (y0 + 1 < G);
+        const bool vz0 = (z0 >= 0) & (z0 < G), vz1 = (z0 + 1 >= 0) & (z0 + 1 < G);
+        const int cx0 = min(max(x0, 0), G - 1), cx1 = min(max(x0 + 1, 0), G - 1);
+        const int cy0 = min(max(y0, 0), G - 1), cy1 = min(max(y0 + 1, 0), G - 1);
+        const int cz0 = min(max(z0, 0), G - 1), cz1 = min(max(z0 + 1, 0), G - 1);
+        const float* vb = vol + (size_t)b * G * GG;
+        const float v000 = vb[cz0 * GG + cy0 * G + cx0], v001 = vb[cz0 * GG + cy0 * G + cx1];
+        const float v010 = vb[cz0 * GG + cy1 * G + cx0], v011 = vb[cz0 * GG + cy1 * G + cx1];
+        const float v100 = vb[cz1 * GG + cy0 * G + cx0], v101 = vb[cz1 * GG + cy0 * G + cx1];
+        const float v110 = vb[cz1 * GG + cy1 * G + cx0], v111 = vb[cz1 * GG + cy1 * G + cx1];
+        float w = 0.f;
+        w += (vz0 & vy0 & vx0) ? v000 * (wx0 * wy0 * wz0) : 0.f;
+        w += (vz0 & vy0 & vx1) ? v001 * (wx1 * wy0 * wz0) : 0.f;
+        w += (vz0 & vy1 & vx0) ? v010 * (wx0 * wy1 * wz0) : 0.f;
+        w += (vz0 & vy1 & vx1) ? v011 * (wx1 * wy1 * wz0) : 0.f;
+        w += (vz1 & vy0 & vx0) ? v100 * (wx0 * wy0 * wz1) : 0.f;
+        w += (vz1 & vy0 & vx1) ? v101 * (wx1 * wy0 * wz1) : 0.f;
+        w += (vz1 & vy1 & vx0) ? v110 * (wx0 * wy1 * wz1) : 0.f;
+        w += (vz1 & vy1 & vx1) ? v111 * (wx1 * wy1 * wz1) : 0.f;
+        wsum += w;
+        ax += w * qx;
+        ay += w * qy;
+        az += w * qz;
+        if (WRITE_BMW) bmw[p * B + b] = w;
+    }
+    const float den = fmaxf(wsum, 0.0001f);
+    z_vals[p] = z;
+    x_skel[p * 3 + 0] = ax / den;
+    x_skel[p * 3 + 1] = ay / den;
+    x_skel[p * 3 + 2] = az / den;
+    fg_mask[p] = wsum;
+}
+
+}  // namespace hnrf
+
+extern "C" int hnrf_sample_warp_fwd(const float* rays_o, const float* rays_d,
+                                    const float* near, const float* far, const float* t_rand,
+                                    const float* motion_Rs, const float* motion_Ts,
+                                    const float* vol, const float* bbox_min, const float* bbox_scale,
+                                    int64_t R, int S, int B, int G,
+                                    float* z_vals, float* x_skel, float* fg_mask, float* bmw,
+                                    void* stream) {
+    using namespace hnrf;
+    HNRF_REQUIRE(rays_o && rays_d && near && far && motion_Rs && motion_Ts && vol && bbox_min && bbox_scale,
+                 HNRF_E_ARG, "hnrf_sample_warp_fwd: null input pointer");
+    HNRF_REQUIRE(z_vals && x_skel && fg_mask, HNRF_E_ARG, "hnrf_sample_warp_fwd: null output pointer");
+    HNRF_REQUIRE(R >= 0 && S >= 2 && B >= 1 && G >= 2 && G <= 1024, HNRF_E_ARG,
+                 "hnrf_sample_warp_fwd: bad dims R=%lld S=%d B=%d G=%d", (long long)R, S, B, G);
+    if (R == 0) return HNRF_OK;
+    const int64_t P = R * (int64_t)S;
+    const int64_t blocks = (P + 255) / 256;
+    HNRF_REQUIRE(blocks < (int64_t)2147483647, HNRF_E_ARG, "hnrf_sample_warp_fwd: too many samples");
+    hipStream_t st = (hipStream_t)stream;
+    if (bmw)
+        hipLaunchKernelGGL(sample_warp_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, st, rays_o, rays_d, near,
+                           far, t_rand, motion_Rs, motion_Ts, vol, bbox_min, bbox_scale, P, S, B, G, z_vals, x_skel,
+                           fg_mask, bmw);
+    else
+        hipLaunchKernelGGL(sample_warp_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, st, rays_o, rays_d, near,
+                           far, t_rand, motion_Rs, motion_Ts, vol, bbox_min, bbox_scale, P, S, B, G, z_vals, x_skel,
+                           fg_mask, bmw);
+    return check_launch("hnrf_sample_warp_fwd");
+}

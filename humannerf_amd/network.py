@@ -1,0 +1,380 @@
+"""``Network`` -- drop-in for the reference's core/nets/human_nerf/network.py.
+
+Same constructor (no arguments, reads the global ``cfg``), same ``forward``
+keyword interface and output keys, same ``state_dict`` key names (including
+the ``.module.`` infix nn.DataParallel inserted in the reference -- checkpoint
+and optimizer-group compatibility), same attribute names the
+optimizer routes learning rates by (optimizer.py:9-34).  Select it with
+``network_module: 'humannerf_amd.network'`` (create_network.py:6-15 loads the
+dotted path with imp.load_source).
+
+What differs is everything underneath: the per-sample work (sampling, LBS warp,
+both MLPs, compositing) runs in the hand-written HIP kernels of libhnrf.so, one
+process per GPU, whole renderer replicated on every GPU.  The reference's
+primary/secondary GPU split and its per-call parameter broadcast
+(network.py:68-72,115-119) do not exist here; ``deploy_mlps_to_secondary_gpus``
+is kept as a no-op.  Per-frame work that is a few KFLOP (pose refinement,
+kinematic chain, 4x4 inverses) and the once-per-frame weight-volume decoder stay
+in PyTorch-ROCm.
+
+Only the default-config branches are implemented; anything else raises.
+"""
+import math
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import ops
+from .config import cfg, amd_option
+
+SMPL_PARENT = [-1, 0, 0, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 9, 9, 12, 13, 14, 16,
+               17, 18, 19, 20, 21]          # core/utils/network_util.py:91-94
+
+
+# --------------------------------------------------------------------------- init
+def _xavier_like(layer, next_act):
+    """Initialisation with the distribution of the reference's initseq/initmod
+    (core/utils/network_util.py:163-290): U(+-sqrt(3) gain sqrt(2/((n_in+n_out) k)))
+    with k = kernel volume / stride volume for transposed convs, zero bias, and the
+    2x2x2 block-replicated kernel for stride-2 ConvTranspose3d."""
+    if isinstance(next_act, nn.ReLU):
+        gain = math.sqrt(2.0)
+    elif isinstance(next_act, nn.LeakyReLU):
+        gain = math.sqrt(2.0 / (1.0 + next_act.negative_slope ** 2))
+    else:
+        gain = 1.0
+    if isinstance(layer, nn.Linear):
+        fan = layer.in_features + layer.out_features
+    elif isinstance(layer, nn.ConvTranspose3d):
+        k = layer.kernel_size[0] * layer.kernel_size[1] * layer.kernel_size[2]
+        k //= layer.stride[0] * layer.stride[1] * layer.stride[2]
+        fan = (layer.in_channels + layer.out_channels) * k
+    else:
+        return
+    bound = gain * math.sqrt(2.0 / fan) * math.sqrt(3.0)
+    with torch.no_grad():
+        layer.weight.uniform_(-bound, bound)
+        if layer.bias is not None:
+            layer.bias.zero_()
+        if isinstance(layer, nn.ConvTranspose3d):
+            w = layer.weight
+            base = w[:, :, 0::2, 0::2, 0::2].clone()
+            for a in (0, 1):
+                for b in (0, 1):
+                    for c in (0, 1):
+                        w[:, :, a::2, b::2, c::2] = base
+
+
+def _init_sequence(mods):
+    mods = list(mods)
+    for cur, nxt in zip(mods, mods[1:] + [None]):
+        _xavier_like(cur, nxt)
+
+
+def _tiny_last_layer(layer, val=1e-5):
+    with torch.no_grad():
+        layer.weight.uniform_(-val, val)
+        layer.bias.zero_()
+
+
+class _Replicated(nn.Module):
+    """Stands where the reference has nn.DataParallel(mlp): only there to keep
+    the ``<name>.module.<...>`` parameter names."""
+
+    def __init__(self, module):
+        super().__init__()
+        self.module = module
+
+
+# --------------------------------------------------------------------------- parts
+class _NonRigidParams(nn.Module):
+    """Parameters of NonRigidMotionMLP (non_rigid_motion_mlps/mlp_offset.py:9-71)."""
+
+    def __init__(self, pos_embed_size, condition_code_size, mlp_width, mlp_depth, skips):
+        super().__init__()
+        if not (pos_embed_size == 36 and condition_code_size == 69 and mlp_width == 128
+                and mlp_depth == 6 and list(skips) == [4]):
+            raise NotImplementedError('only the default non-rigid MLP (6x128, skip 4, PE36, cond 69) is built')
+        mods = [nn.Linear(pos_embed_size + condition_code_size, mlp_width), nn.ReLU()]
+        for i in range(1, mlp_depth):
+            n_in = mlp_width + pos_embed_size if i in skips else mlp_width
+            mods += [nn.Linear(n_in, mlp_width), nn.ReLU()]
+        mods += [nn.Linear(mlp_width, 3)]
+        self.block_mlps = nn.ModuleList(mods)
+        _init_sequence(self.block_mlps)
+        _tiny_last_layer(self.block_mlps[-1])          # mlp_offset.py:60-66
+
+    def linears(self):
+        return [m for m in self.block_mlps if isinstance(m, nn.Linear)]
+
+
+class _CanonicalParams(nn.Module):
+    """Parameters of CanonicalMLP default branch (canonical_mlps/mlp_rgb_sigma.py:64-99)."""
+
+    def __init__(self, input_ch, mlp_depth, mlp_width, skips):
+        super().__init__()
+        if not (input_ch == 63 and mlp_depth == 8 and mlp_width == 256 and list(skips) == [4]):
+            raise NotImplementedError('only the default canonical MLP (8x256, skip 4, PE63) is built')
+        mods = [nn.Linear(input_ch, mlp_width), nn.ReLU()]
+        for i in range(mlp_depth - 1):
+            n_in = mlp_width + input_ch if i in skips else mlp_width
+            mods += [nn.Linear(n_in, mlp_width), nn.ReLU()]
+        self.pts_linears = nn.ModuleList(mods)
+        _init_sequence(self.pts_linears)
+        self.output_linear = nn.Sequential(nn.Linear(mlp_width, 4))
+        _init_sequence(self.output_linear)
+
+    def linears(self):
+        return [m for m in self.pts_linears if isinstance(m, nn.Linear)] + [self.output_linear[0]]
+
+
+class _ConvDecoder3D(nn.Module):
+    """core/utils/network_util.py:12-50."""
+
+    def __init__(self, embedding_size, volume_size, voxel_channels):
+        super().__init__()
+        self.block_mlp = nn.Sequential(nn.Linear(embedding_size, 1024), nn.LeakyReLU(0.2))
+        convs, cin, cout = [], 1024, 512
+        for _ in range(int(math.log2(volume_size)) - 1):
+            convs += [nn.ConvTranspose3d(cin, cout, 4, 2, 1), nn.LeakyReLU(0.2)]
+            if cin == cout:
+                cout = cin // 2
+            else:
+                cin = cout
+        convs.append(nn.ConvTranspose3d(cin, voxel_channels, 4, 2, 1))
+        self.block_conv = nn.Sequential(*convs)
+        _init_sequence(self.block_mlp)
+        _init_sequence(self.block_conv)
+
+    def forward(self, embedding):
+        return self.block_conv(self.block_mlp(embedding).view(-1, 1024, 1, 1, 1))
+
+
+class MotionWeightVolumeDecoder(nn.Module):
+    """mweight_vol_decoders/deconv_vol_decoder.py:8-33 (stays PyTorch/MIOpen:
+    9 GFLOP once per frame against 40 TFLOP of per-sample work)."""
+
+    def __init__(self, embedding_size=256, volume_size=32, total_bones=24):
+        super().__init__()
+        self.const_embedding = nn.Parameter(torch.randn(embedding_size), requires_grad=True)
+        self.decoder = _ConvDecoder3D(embedding_size, volume_size, total_bones + 1)
+
+    def forward(self, motion_weights_priors, **_):
+        dec = self.decoder(self.const_embedding[None, ...])
+        return F.softmax(dec + torch.log(motion_weights_priors), dim=1)
+
+
+class BodyPoseRefiner(nn.Module):
+    """pose_decoders/mlp_delta_body_pose.py:7-41."""
+
+    def __init__(self, embedding_size=69, mlp_width=256, mlp_depth=4, total_bones=24):
+        super().__init__()
+        mods = [nn.Linear(embedding_size, mlp_width), nn.ReLU()]
+        for _ in range(mlp_depth - 1):
+            mods += [nn.Linear(mlp_width, mlp_width), nn.ReLU()]
+        self.total_bones = total_bones - 1
+        mods += [nn.Linear(mlp_width, 3 * self.total_bones)]
+        self.block_mlps = nn.Sequential(*mods)
+        _init_sequence(self.block_mlps)
+        _tiny_last_layer(self.block_mlps[-1])
+
+    def forward(self, pose_input):
+        rvec = self.block_mlps(pose_input).view(-1, 3)
+        return {'Rs': rodrigues(rvec).view(-1, self.total_bones, 3, 3),
+                'rvec': rvec.view(-1, self.total_bones, 3)}
+
+
+def rodrigues(rvec):
+    """Batch Rodrigues with theta = sqrt(1e-5 + |r|^2) (network_util.py:57-83)."""
+    theta = torch.sqrt(1e-5 + torch.sum(rvec ** 2, dim=1))
+    r = rvec / theta[:, None]
+    c, s = torch.cos(theta), torch.sin(theta)
+    x, y, z = r[:, 0], r[:, 1], r[:, 2]
+    oc = 1. - c
+    return torch.stack((x * x + (1. - x * x) * c, x * y * oc - z * s, x * z * oc + y * s,
+                        x * y * oc + z * s, y * y + (1. - y * y) * c, y * z * oc - x * s,
+                        x * z * oc - y * s, y * z * oc + x * s, z * z + (1. - z * z) * c), dim=1).view(-1, 3, 3)
+
+
+def motion_basis(dst_Rs, dst_Ts, cnl_gtfms):
+    """MotionBasisComputer.forward (network_util.py:125-156) for one frame:
+    (B,3,3),(B,3),(B,4,4) -> (B,3,3),(B,3)."""
+    B = dst_Rs.shape[0]
+    G = torch.zeros(B, 4, 4, dtype=dst_Rs.dtype, device=dst_Rs.device)
+    G[:, :3, :3] = dst_Rs
+    G[:, :3, 3] = dst_Ts
+    G[:, 3, 3] = 1.0
+    chain = [G[0]]
+    for i in range(1, B):
+        chain.append(torch.matmul(chain[SMPL_PARENT[i]], G[i]))
+    f_mtx = torch.matmul(cnl_gtfms, torch.inverse(torch.stack(chain)))
+    return f_mtx[:, :3, :3].contiguous(), f_mtx[:, :3, 3].contiguous()
+
+
+def hann_window_weights(iter_val, multires, kick_in_iter, full_band_iter):
+    """Per-band weights of the coarse-to-fine window (hannw_fourier.py:26-40),
+    fp32 on the host like the reference's float32 constants."""
+    kick = torch.tensor(float(kick_in_iter), dtype=torch.float32)
+    t = torch.clamp(torch.tensor(float(iter_val), dtype=torch.float32) - kick, min=0.)
+    N = full_band_iter - kick_in_iter
+    alpha = torch.tensor(float(multires), dtype=torch.float32) if N == 0 else multires * t / N
+    k = torch.arange(multires, dtype=torch.float32)
+    return (1. - torch.cos(math.pi * torch.clamp(alpha - k, min=0., max=1.))) / 2.
+
+
+def _versions(params):
+    return tuple((p.data_ptr(), p._version) for p in params)
+
+
+# --------------------------------------------------------------------------- network
+class Network(nn.Module):
+    def __init__(self):
+        super().__init__()
+        if cfg.get('non_rigid_motion_model', 'mlp') != 'mlp':
+            raise NotImplementedError('non_rigid_motion_model != mlp is outside the hot path (SURVEY.md section 2.1 #4)')
+        cm, nr = cfg.canonical_mlp, cfg.non_rigid_motion_mlp
+        if cm.get('view_dir', False) or cm.get('pose_color', 'wo') != 'wo' or cm.get('multihead', {}).get('enable', False):
+            raise NotImplementedError('only the default canonical MLP branch is built')
+        self.total_bones = cfg.total_bones
+
+        self.mweight_vol_decoder = MotionWeightVolumeDecoder(
+            embedding_size=cfg.mweight_volume.embedding_size,
+            volume_size=cfg.mweight_volume.volume_size,
+            total_bones=cfg.total_bones)
+        self.non_rigid_mlp = _Replicated(_NonRigidParams(
+            pos_embed_size=6 * nr.multires, condition_code_size=nr.condition_code_size,
+            mlp_width=nr.mlp_width, mlp_depth=nr.mlp_depth, skips=nr.skips))
+        self.cnl_mlp = _Replicated(_CanonicalParams(
+            input_ch=3 + 6 * cm.multires, mlp_depth=cm.mlp_depth, mlp_width=cm.mlp_width, skips=[4]))
+        if not cfg.get('pose_decoder_off', False):
+            self.pose_decoder = BodyPoseRefiner(
+                embedding_size=cfg.pose_decoder.embedding_size, mlp_width=cfg.pose_decoder.mlp_width,
+                mlp_depth=cfg.pose_decoder.mlp_depth, total_bones=cfg.total_bones)
+        self._cnl_pack = None     # (key, packed image)
+        self._nr_pack_buf = None
+        self._vol_cache = None    # (key, priors, volume)
+
+    # reference API ---------------------------------------------------------
+    def deploy_mlps_to_secondary_gpus(self):
+        """No-op: every GPU runs the whole renderer (network.py:161-166)."""
+        return self
+
+    # packed-weight caches ----------------------------------------------------
+    def _mlp_mode(self):
+        return amd_option('mlp_mode', 'f32')
+
+    def _canonical_packed(self):
+        lin = self.cnl_mlp.module.linears()
+        ws, bs = [l.weight for l in lin], [l.bias for l in lin]
+        key = (self._mlp_mode(),) + _versions(ws + bs)
+        if self._cnl_pack is None or self._cnl_pack[0] != key:
+            packed = ops.canonical_pack([w.detach() for w in ws], [b.detach() for b in bs], self._mlp_mode(),
+                                        out=None if self._cnl_pack is None else self._cnl_pack[1])
+            self._cnl_pack = (key, packed)
+        return self._cnl_pack[1]
+
+    def _nonrigid_packed(self, cond):
+        lin = self.non_rigid_mlp.module.linears()
+        self._nr_pack_buf = ops.nonrigid_pack([l.weight.detach() for l in lin], [l.bias.detach() for l in lin],
+                                              cond.detach().contiguous(), self._mlp_mode(), out=self._nr_pack_buf)
+        return self._nr_pack_buf
+
+    def _weight_volume(self, priors):
+        """(B+1,G,G,G) softmax volume; cached across frames in eval mode."""
+        params = list(self.mweight_vol_decoder.parameters())
+        use_cache = (not self.training) and (not torch.is_grad_enabled()) and amd_option('cache_weight_volume', True)
+        key = _versions(params)
+        if use_cache and self._vol_cache is not None and self._vol_cache[0] == key \
+                and self._vol_cache[1].shape == priors.shape and torch.equal(self._vol_cache[1], priors):
+            return self._vol_cache[2]
+        vol = self.mweight_vol_decoder(motion_weights_priors=priors[None])[0].contiguous()
+        if use_cache:
+            self._vol_cache = (key, priors.clone(), vol)
+        return vol
+
+    # forward -------------------------------------------------------------------
+    def forward(self, rays, dst_Rs, dst_Ts, cnl_gtfms, motion_weights_priors, dst_posevec=None,
+                near=None, far=None, iter_val=1e7, cnl_bbox_min_xyz=None, cnl_bbox_scale_xyz=None,
+                bgcolor=None, t_rand=None, **kwargs):
+        """network.py:647-789.  Extra keyword ``t_rand`` (N,S) injects the
+        stratified-sampling uniforms (parity tests); unknown kwargs are ignored
+        like the reference's **kwargs."""
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            raise NotImplementedError(
+                'training through the HIP path needs the backward kernels (not built in this round); '
+                'call under torch.no_grad() for rendering')
+        iter_val = float(iter_val)
+        dev = dst_Rs.device
+        f32 = lambda t: t.to(dtype=torch.float32)
+        dst_Rs, dst_Ts, dst_posevec = f32(dst_Rs), f32(dst_Ts), f32(dst_posevec)
+        cnl_gtfms, priors = f32(cnl_gtfms), f32(motion_weights_priors)
+
+        # pose refinement (network.py:667-688)
+        if iter_val >= cfg.pose_decoder.get('kick_in_iter', 0) and not cfg.get('pose_decoder_off', False):
+            dR = self.pose_decoder(dst_posevec[None])['Rs'][0]            # (23,3,3)
+            dst_Rs = torch.cat([dst_Rs[0:1], torch.matmul(dst_Rs[1:], dR)], dim=0)
+
+        ignore_nr = bool(cfg.ignore_non_rigid_motions)
+        nr_cfg = cfg.non_rigid_motion_mlp
+        cond = dst_posevec
+        if iter_val < nr_cfg.kick_in_iter:
+            cond = torch.zeros_like(cond) * cond                            # network.py:735-737
+        motion_Rs, motion_Ts = motion_basis(dst_Rs, dst_Ts, cnl_gtfms)
+        vol = self._weight_volume(priors)
+        self.motion_weights_vol = vol
+
+        mode = self._mlp_mode()
+        cnl_packed = self._canonical_packed()
+        nr_packed, hann_w = None, None
+        if not ignore_nr:
+            nr_packed = self._nonrigid_packed(cond)
+            hann_w = hann_window_weights(iter_val, nr_cfg.multires, nr_cfg.kick_in_iter,
+                                         nr_cfg.full_band_iter).to(dev)
+
+        rays_o, rays_d = rays[0], rays[1]
+        rays_shape = rays_d.shape
+        rays_o = f32(rays_o).reshape(-1, 3).contiguous()
+        rays_d = f32(rays_d).reshape(-1, 3).contiguous()
+        N = rays_o.shape[0]
+        near = f32(near).reshape(-1).contiguous()
+        far = f32(far).reshape(-1).contiguous()
+        bbox_min = f32(cnl_bbox_min_xyz).contiguous()
+        bbox_scale = f32(cnl_bbox_scale_xyz).contiguous()
+        bg = f32(bgcolor).contiguous()
+        S = int(cfg.N_samples)
+        if cfg.perturb > 0.:
+            if t_rand is None:
+                t_rand = torch.rand(N, S, device=dev)                       # network.py:468
+            t_rand = f32(t_rand).reshape(N, S).contiguous()
+        else:
+            t_rand = None
+        diag = bool(amd_option('diagnostics', True))
+
+        chunks = []
+        for i in range(0, N, int(cfg.chunk)):                              # network.py:333
+            sl = slice(i, min(i + int(cfg.chunk), N))
+            chunks.append(self._render_rays(rays_o[sl], rays_d[sl], near[sl], far[sl],
+                                            None if t_rand is None else t_rand[sl],
+                                            motion_Rs, motion_Ts, vol, bbox_min, bbox_scale, hann_w,
+                                            nr_packed, cnl_packed, bg, S, mode, diag))
+        out = {k: (torch.cat([c[k] for c in chunks], 0) if len(chunks) > 1 else chunks[0][k]) for k in chunks[0]}
+        lead = list(rays_shape[:-1])
+        return {k: v.reshape(lead + list(v.shape[1:])) for k, v in out.items()}
+
+    def _render_rays(self, rays_o, rays_d, near, far, t_rand, motion_Rs, motion_Ts, vol, bbox_min, bbox_scale,
+                     hann_w, nr_packed, cnl_packed, bg, S, mode, diag):
+        """network.py:474-602 for one ray chunk."""
+        if not diag:
+            return ops.render_rays(rays_o, rays_d, near, far, t_rand, motion_Rs, motion_Ts, vol, bbox_min,
+                                   bbox_scale, hann_w, nr_packed, cnl_packed, bg, S, mode)
+        z, x_skel, mask, bmw = ops.sample_warp(rays_o, rays_d, near, far, t_rand, motion_Rs, motion_Ts, vol,
+                                               bbox_min, bbox_scale, S, want_bmw=True)
+        if nr_packed is not None:
+            xyz, offsets = ops.nonrigid(x_skel, hann_w, nr_packed, mode, want_offsets=True)
+        else:
+            xyz, offsets = x_skel, torch.zeros_like(x_skel)                 # network.py:276-277
+        raw = ops.canonical(xyz, cnl_packed, mode)
+        out = ops.composite(raw, mask, z, rays_d, xyz, bg, diagnostics=True)
+        out.update(xyz_on_rays=xyz, backward_motion_weights=bmw, offsets=offsets)
+        return out

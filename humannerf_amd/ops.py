@@ -1,0 +1,178 @@
+"""Host-side operators of the hot path: thin torch-tensor wrappers over the C ABI.
+
+PyTorch is plumbing here (device memory, streams); all arithmetic of the path
+happens in libhnrf.so.  Every op requires CUDA(ROCm) fp32 contiguous tensors and
+raises otherwise -- there is no eager fallback.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+
+MLP_MODES = {'f32': 0, 'f16x3': 1}
+
+
+def _ptr(t):
+    return 0 if t is None else t.data_ptr()
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _chk(*tensors):
+    for t in tensors:
+        if t is None:
+            continue
+        if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()):
+            raise _lib.HnrfError(
+                f'hot-path operand must be a contiguous fp32 tensor on the GPU, got '
+                f'{t.dtype} {t.device} contiguous={t.is_contiguous()} shape={tuple(t.shape)}')
+
+
+def _ptr_array(tensors):
+    return (ctypes.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
+
+
+def sample_warp(rays_o, rays_d, near, far, t_rand, motion_Rs, motion_Ts, vol, bbox_min, bbox_scale,
+                n_samples, want_bmw=False):
+    """K1 (network.py:455-471, 499, 392-444).  Returns z_vals (R,S), x_skel (R,S,3),
+    fg_mask (R,S), bmw (R,S,B) or None."""
+    lib = _lib.load()
+    near, far = near.reshape(-1), far.reshape(-1)
+    _chk(rays_o, rays_d, near, far, t_rand, motion_Rs, motion_Ts, vol, bbox_min, bbox_scale)
+    R, S = rays_o.shape[0], int(n_samples)
+    B = motion_Rs.shape[0]
+    G = vol.shape[-1]
+    assert vol.shape[0] >= B and vol.shape[1] == vol.shape[2] == G
+    assert rays_d.shape == (R, 3) and near.numel() == R and far.numel() == R
+    if t_rand is not None:
+        assert t_rand.shape == (R, S)
+    dev = rays_o.device
+    z = torch.empty(R, S, device=dev)
+    x_skel = torch.empty(R, S, 3, device=dev)
+    mask = torch.empty(R, S, device=dev)
+    bmw = torch.empty(R, S, B, device=dev) if want_bmw else None
+    _lib.check(lib.hnrf_sample_warp_fwd(_ptr(rays_o), _ptr(rays_d), _ptr(near), _ptr(far), _ptr(t_rand),
+                                        _ptr(motion_Rs), _ptr(motion_Ts), _ptr(vol), _ptr(bbox_min),
+                                        _ptr(bbox_scale), R, S, B, G, _ptr(z), _ptr(x_skel), _ptr(mask),
+                                        _ptr(bmw), _stream()), 'hnrf_sample_warp_fwd')
+    return z, x_skel, mask, bmw
+
+
+def nonrigid_pack(weights, biases, cond, mode='f32', out=None):
+    """Pack block_mlps.{0..12} (7 Linear layers) + the frame's condition code."""
+    lib = _lib.load()
+    m = MLP_MODES[mode]
+    cond = cond.reshape(-1)
+    _chk(*weights, *biases, cond)
+    assert len(weights) == 7 and len(biases) == 7 and cond.numel() == 69
+    shapes = [(128, 105), (128, 128), (128, 128), (128, 128), (128, 164), (128, 128), (3, 128)]
+    for w, b, s in zip(weights, biases, shapes):
+        if tuple(w.shape) != s or b.numel() != s[0]:
+            raise _lib.HnrfError(f'non-rigid MLP layer shape {tuple(w.shape)} != {s}: only the default '
+                                 f'architecture (default.yaml:142-165) is built')
+    nbytes = lib.hnrf_nonrigid_packed_bytes(m)
+    if out is None:
+        out = torch.empty(nbytes // 4, device=cond.device)
+    assert out.numel() * 4 >= nbytes
+    _lib.check(lib.hnrf_nonrigid_pack(_ptr_array(weights), _ptr_array(biases), _ptr(cond), m, _ptr(out),
+                                      _stream()), 'hnrf_nonrigid_pack')
+    return out
+
+
+def nonrigid(x_skel, hann_w, packed, mode='f32', want_offsets=False):
+    """K2 (hannw_fourier.py:21-49 + mlp_offset.py:74-114).  x_skel (...,3)."""
+    lib = _lib.load()
+    _chk(x_skel, hann_w, packed)
+    P = x_skel.numel() // 3
+    xyz = torch.empty_like(x_skel)
+    offsets = torch.empty_like(x_skel) if want_offsets else None
+    _lib.check(lib.hnrf_nonrigid_fwd(_ptr(x_skel), _ptr(hann_w), _ptr(packed), MLP_MODES[mode], P, _ptr(xyz),
+                                     _ptr(offsets), _stream()), 'hnrf_nonrigid_fwd')
+    return xyz, offsets
+
+
+def canonical_pack(weights, biases, mode='f32', out=None):
+    """Pack pts_linears.{0..14} (8 layers) + output_linear.0."""
+    lib = _lib.load()
+    m = MLP_MODES[mode]
+    _chk(*weights, *biases)
+    assert len(weights) == 9 and len(biases) == 9
+    shapes = [(256, 63)] + [(256, 256)] * 4 + [(256, 319)] + [(256, 256)] * 2 + [(4, 256)]
+    for w, b, s in zip(weights, biases, shapes):
+        if tuple(w.shape) != s or b.numel() != s[0]:
+            raise _lib.HnrfError(f'canonical MLP layer shape {tuple(w.shape)} != {s}: only the default '
+                                 f'architecture (default.yaml:51-57) is built')
+    nbytes = lib.hnrf_canonical_packed_bytes(m)
+    if out is None:
+        out = torch.empty(nbytes // 4, device=weights[0].device)
+    assert out.numel() * 4 >= nbytes
+    _lib.check(lib.hnrf_canonical_pack(_ptr_array(weights), _ptr_array(biases), m, _ptr(out), _stream()),
+               'hnrf_canonical_pack')
+    return out
+
+
+def canonical(xyz, packed, mode='f32'):
+    """K3 (fourier.py:9-38 + mlp_rgb_sigma.py:132-198).  xyz (...,3) -> raw (...,4)."""
+    lib = _lib.load()
+    _chk(xyz, packed)
+    P = xyz.numel() // 3
+    raw = torch.empty(*xyz.shape[:-1], 4, device=xyz.device)
+    _lib.check(lib.hnrf_canonical_fwd(_ptr(xyz), _ptr(packed), MLP_MODES[mode], P, _ptr(raw), _stream()),
+               'hnrf_canonical_fwd')
+    return raw
+
+
+def composite(raw, fg_mask, z_vals, rays_d, xyz, bgcolor, diagnostics=True):
+    """K4 (network.py:355-388).  Returns dict with rgb/alpha/depth and, when
+    ``diagnostics``, weights_on_rays, rgb_on_rays, cnl_xyz, cnl_rgb, cnl_weight."""
+    lib = _lib.load()
+    _chk(raw, fg_mask, z_vals, rays_d, xyz, bgcolor)
+    R, S = z_vals.shape
+    dev = raw.device
+    out = {'rgb': torch.empty(R, 3, device=dev), 'alpha': torch.empty(R, device=dev),
+           'depth': torch.empty(R, device=dev)}
+    if diagnostics:
+        out.update(weights_on_rays=torch.empty(R, S, device=dev), rgb_on_rays=torch.empty(R, S, 3, device=dev),
+                   cnl_xyz=torch.empty(R, 3, device=dev), cnl_rgb=torch.empty(R, 3, device=dev),
+                   cnl_weight=torch.empty(R, device=dev))
+    g = out.get
+    _lib.check(lib.hnrf_composite_fwd(_ptr(raw), _ptr(fg_mask), _ptr(z_vals), _ptr(rays_d), _ptr(xyz),
+                                      _ptr(bgcolor), R, S, _ptr(out['rgb']), _ptr(out['alpha']),
+                                      _ptr(out['depth']), _ptr(g('weights_on_rays')), _ptr(g('rgb_on_rays')),
+                                      _ptr(g('cnl_xyz')), _ptr(g('cnl_rgb')), _ptr(g('cnl_weight')), _stream()),
+               'hnrf_composite_fwd')
+    return out
+
+
+def render_workspace_bytes(R, S):
+    return _lib.load().hnrf_render_workspace_bytes(int(R), int(S))
+
+
+def render_rays(rays_o, rays_d, near, far, t_rand, motion_Rs, motion_Ts, vol, bbox_min, bbox_scale,
+                hann_w, nr_packed, cnl_packed, bgcolor, n_samples, mode='f32', workspace=None, out=None):
+    """The whole path for one ray chunk (network.py:474-602) with only the
+    rgb/alpha/depth outputs; intermediates live in ``workspace``."""
+    lib = _lib.load()
+    near, far = near.reshape(-1), far.reshape(-1)
+    _chk(rays_o, rays_d, near, far, t_rand, motion_Rs, motion_Ts, vol, bbox_min, bbox_scale, hann_w,
+         nr_packed, cnl_packed, bgcolor)
+    R, S = rays_o.shape[0], int(n_samples)
+    need = lib.hnrf_render_workspace_bytes(R, S)
+    if workspace is None:
+        workspace = torch.empty(need // 4 + 64, device=rays_o.device)
+    assert workspace.numel() * workspace.element_size() >= need
+    dev = rays_o.device
+    if out is None:
+        out = {'rgb': torch.empty(R, 3, device=dev), 'alpha': torch.empty(R, device=dev),
+               'depth': torch.empty(R, device=dev)}
+    _lib.check(lib.hnrf_render_rays_fwd(_ptr(rays_o), _ptr(rays_d), _ptr(near), _ptr(far), _ptr(t_rand),
+                                        _ptr(motion_Rs), _ptr(motion_Ts), _ptr(vol), _ptr(bbox_min),
+                                        _ptr(bbox_scale), _ptr(hann_w), _ptr(nr_packed), _ptr(cnl_packed),
+                                        _ptr(bgcolor), MLP_MODES[mode], R, S, motion_Rs.shape[0], vol.shape[-1],
+                                        _ptr(workspace), workspace.numel() * workspace.element_size(),
+                                        _ptr(out['rgb']), _ptr(out['alpha']), _ptr(out['depth']), _stream()),
+               'hnrf_render_rays_fwd')
+    return out

@@ -1,0 +1,129 @@
+/*
+ * hnrf.h -- C ABI of the MI355X-native HumanNeRF ray-marching path
+ * (libhnrf.so, hand-written HIP for gfx950).
+ *
+ * The reference (ChenYutongTHU/humannerf) is pure Python/PyTorch and has no FFI;
+ * its "operator interface" for this path is the set of methods of
+ * core/nets/human_nerf/network.py::Network.  Each entry point below replaces
+ * the torch-op sequence of one of those methods and cites it.  A maintainer of
+ * the reference binds these with ctypes (INTEGRATION.md shows the stub).
+ *
+ * Conventions:
+ *  - every pointer is a DEVICE pointer to contiguous row-major fp32 unless
+ *    stated otherwise; the caller owns every buffer, the library allocates
+ *    nothing and keeps no state between calls;
+ *  - `stream` is a hipStream_t passed as void*; calls are stream-ordered and
+ *    never synchronise the device or touch the host copy of any buffer;
+ *  - return value 0 = success, negative = error (see HNRF_E_*); the message is
+ *    available from hnrf_last_error() (thread-local); nothing throws or exits;
+ *  - nullable outputs may be passed as NULL to skip their HBM writes.
+ */
+#ifndef HNRF_H
+#define HNRF_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HNRF_OK            0
+#define HNRF_E_ARG        -1   /* null pointer / bad dimension            */
+#define HNRF_E_UNSUPPORTED -2  /* layer shape / mode not built            */
+#define HNRF_E_LAUNCH     -3   /* hipLaunch / hipGetLastError failed      */
+#define HNRF_E_WORKSPACE  -4   /* workspace too small                     */
+
+/* arithmetic of the per-sample MLP GEMMs */
+#define HNRF_MLP_F32    0      /* v_mfma_f32_32x32x2_f32: exact fp32 fma chain   */
+#define HNRF_MLP_F16X3  1      /* split-fp16 (hi+lo) inputs, 3 MFMAs, fp32 accum */
+
+int         hnrf_abi_version(void);
+const char* hnrf_last_error(void);
+
+/* ---- K1: z-sampling + inverse-LBS warp ------------------------------------
+ * Replaces Network._get_samples_along_ray / _stratified_sampling
+ * (network.py:455-471), pts = o + d*z (network.py:499) and
+ * Network._sample_motion_fields (network.py:392-444).
+ *  rays_o, rays_d [R,3]; near, far [R]; t_rand [R,S] or NULL (perturb == 0);
+ *  motion_Rs [B,3,3], motion_Ts [B,3]; vol [>=B, G,G,G] (background channel, if
+ *  present, is not read); bbox_min, bbox_scale [3]   -- all device pointers.
+ * Outputs: z_vals [R,S], x_skel [R,S,3], fg_mask [R,S] (= sum of weights,
+ *  unclamped), bmw [R,S,B] or NULL (unnormalised per-bone weights). */
+int hnrf_sample_warp_fwd(const float* rays_o, const float* rays_d,
+                         const float* near, const float* far, const float* t_rand,
+                         const float* motion_Rs, const float* motion_Ts,
+                         const float* vol, const float* bbox_min, const float* bbox_scale,
+                         int64_t R, int S, int B, int G,
+                         float* z_vals, float* x_skel, float* fg_mask, float* bmw,
+                         void* stream);
+
+/* ---- K2: non-rigid motion MLP ---------------------------------------------
+ * Replaces hannw_fourier embed (embedders/hannw_fourier.py:21-49) +
+ * NonRigidMotionMLP.forward (non_rigid_motion_mlps/mlp_offset.py:74-114) as
+ * called from Network._apply_mlp_kernals (network.py:264-275).
+ * Default architecture only: 6 x 128, skip [h | PE36] at layer 4, out 3,
+ * condition code 69 (one vector per frame, folded into the first bias).
+ *
+ * hnrf_nonrigid_pack: weights[7], biases[7] are the nn.Linear tensors
+ *  block_mlps.{0,2,...,12} in (out,in) layout; cond [69] is the (possibly
+ *  zeroed, network.py:735-737) condition code.  Writes the MFMA-ordered weight
+ *  image into `packed` (hnrf_nonrigid_packed_bytes(mode) bytes).  Re-run after
+ *  every parameter update or new frame (cond changes per frame). */
+size_t hnrf_nonrigid_packed_bytes(int mode);
+int hnrf_nonrigid_pack(const float* const* weights, const float* const* biases,
+                       const float* cond, int mode, void* packed, void* stream);
+/*  x_skel [P,3]; hann_w [6] device pointer (window weights, hannw_fourier.py:
+ *  26-40).  Outputs xyz = x_skel + offset [P,3]; offsets [P,3] or NULL. */
+int hnrf_nonrigid_fwd(const float* x_skel, const float* hann_w, const void* packed,
+                      int mode, int64_t P, float* xyz, float* offsets, void* stream);
+
+/* ---- K3: canonical MLP ----------------------------------------------------
+ * Replaces fourier embed (embedders/fourier.py:9-38) + CanonicalMLP.forward
+ * default branch (canonical_mlps/mlp_rgb_sigma.py:132-198) as called from
+ * Network._apply_mlp_kernals (network.py:305-315).
+ * Default architecture only: PE63 -> 8 x 256, skip [PE63 | h] at layer 5, out 4.
+ *  weights[9], biases[9]: pts_linears.{0,...,14} then output_linear.0. */
+size_t hnrf_canonical_packed_bytes(int mode);
+int hnrf_canonical_pack(const float* const* weights, const float* const* biases,
+                        int mode, void* packed, void* stream);
+/*  xyz [P,3] -> raw [P,4] = (r,g,b,sigma) pre-activation. */
+int hnrf_canonical_fwd(const float* xyz, const void* packed, int mode, int64_t P,
+                       float* raw, void* stream);
+
+/* ---- K4: alpha compositing --------------------------------------------------
+ * Replaces Network._raw2outputs (network.py:355-388).
+ *  raw [R,S,4]; fg_mask [R,S]; z_vals [R,S]; rays_d [R,3]; xyz [R,S,3] (may be
+ *  NULL when cnl_xyz is NULL); bgcolor [3] in 0..255 (device pointer).
+ * Outputs: rgb [R,3], alpha [R], depth [R]; nullable: weights [R,S],
+ *  rgb_on_rays [R,S,3], cnl_xyz [R,3], cnl_rgb [R,3], cnl_weight [R]. */
+int hnrf_composite_fwd(const float* raw, const float* fg_mask, const float* z_vals,
+                       const float* rays_d, const float* xyz, const float* bgcolor,
+                       int64_t R, int S,
+                       float* rgb, float* alpha, float* depth,
+                       float* weights, float* rgb_on_rays,
+                       float* cnl_xyz, float* cnl_rgb, float* cnl_weight,
+                       void* stream);
+
+/* ---- whole path for one ray chunk -------------------------------------------
+ * Replaces Network._render_rays (network.py:474-602): K1 -> K2 -> K3 -> K4 on
+ * `stream`, intermediates in caller-provided workspace
+ * (hnrf_render_workspace_bytes(R,S) bytes, 256-byte aligned).
+ * nr_packed == NULL means cfg.ignore_non_rigid_motions (network.py:264,276-277).
+ * Only rgb/alpha/depth are written (the trainer and the image writers read
+ * nothing else: trainer.py:121, run.py:130). */
+size_t hnrf_render_workspace_bytes(int64_t R, int S);
+int hnrf_render_rays_fwd(const float* rays_o, const float* rays_d,
+                         const float* near, const float* far, const float* t_rand,
+                         const float* motion_Rs, const float* motion_Ts,
+                         const float* vol, const float* bbox_min, const float* bbox_scale,
+                         const float* hann_w, const void* nr_packed, const void* cnl_packed,
+                         const float* bgcolor, int mode,
+                         int64_t R, int S, int B, int G,
+                         void* workspace, size_t workspace_bytes,
+                         float* rgb, float* alpha, float* depth, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HNRF_H */

@@ -1,0 +1,281 @@
+"""Parity of the HIP path (through the C ABI) against the CPU oracle and the
+reference-generated golden fixtures.  Needs an MI355X: ``pytest -m gpu``.
+
+fp32 tolerance of the build (mode 'f32', v_mfma_f32_32x32x2_f32), stated once:
+  per-ray  rgb, alpha            |err| <= 5e-5      (reference's own fp32 noise: 1.0e-5 / 1.5e-5)
+           depth                 |err| <= 4e-4      (values up to ~6; reference noise 9e-5)
+  PSNR(rgb) vs reference         >= 80 dB
+  per-sample positions           |err| <= 1e-4      (reference noise 6e-5 where sum w ~ 1e-4)
+Per-sample colours sit behind a 2^9 positional-encoding band and are compared
+loosely (see tests/test_oracle_golden.py).
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+TOL_RGB, TOL_ALPHA, TOL_DEPTH, TOL_XYZ = 5e-5, 5e-5, 4e-4, 1e-4
+
+
+def dev():
+    assert torch.cuda.is_available(), 'GPU tests need an MI355X'
+    return torch.device('cuda:0')
+
+
+def psnr(a, b):
+    mse = float(np.mean((np.asarray(a, dtype=np.float64) - np.asarray(b, dtype=np.float64)) ** 2))
+    return 200.0 if mse == 0 else -10 * np.log10(mse)
+
+
+@pytest.fixture(scope='module')
+def gpu_net(seeded_params):
+    from humannerf_amd.network import Network
+    net = Network()
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in seeded_params.items()}, strict=True)
+    return net.to(dev()).eval().deploy_mlps_to_secondary_gpus()
+
+
+def frame_to_gpu(fr):
+    keys = ['rays', 'near', 'far', 'dst_Rs', 'dst_Ts', 'cnl_gtfms', 'motion_weights_priors', 'dst_posevec',
+            'cnl_bbox_min_xyz', 'cnl_bbox_scale_xyz', 'bgcolor']
+    d = {k: torch.from_numpy(np.ascontiguousarray(fr[k])).to(dev()) for k in keys}
+    d['head_id'] = torch.tensor(-1)
+    return d
+
+
+# ------------------------------------------------------------------ whole path vs the reference
+CASES = ['eval_s128', 'eval_s64', 'tpose_s128', 'iter0_s128', 'iter5000_s128', 'iter30000_s128', 'perturb_s128']
+
+
+@pytest.mark.parametrize('case', CASES)
+def test_network_matches_reference_golden(case, gpu_net, golden_frame, golden_dir):
+    from humannerf_amd.config import cfg
+    with open(os.path.join(golden_dir, 'meta.json')) as f:
+        m = json.load(f)[case]
+    g = np.load(os.path.join(golden_dir, case + '.npz'))
+    cfg.N_samples, cfg.perturb = m['N_samples'], m['perturb']
+    cfg.ignore_non_rigid_motions = m['ignore_non_rigid_motions']
+    kw = {}
+    if 't_rand' in g.files:
+        kw['t_rand'] = torch.from_numpy(g['t_rand']).to(dev())
+    try:
+        with torch.no_grad():
+            out = gpu_net(**frame_to_gpu(golden_frame), iter_val=m['iter_val'], **kw)
+    finally:
+        cfg.N_samples, cfg.perturb, cfg.ignore_non_rigid_motions = 128, 1.0, False
+    out = {k: v.cpu().numpy() for k, v in out.items()}
+    assert set(out) == {'rgb', 'alpha', 'depth', 'weights_on_rays', 'xyz_on_rays', 'rgb_on_rays', 'cnl_xyz',
+                        'cnl_rgb', 'cnl_weight', 'backward_motion_weights', 'offsets'}
+    n = m['keep_rays']
+    assert out['rgb'].shape == (m['n_rays'], 3) and out['weights_on_rays'].shape == (m['n_rays'], m['N_samples'])
+    assert np.abs(out['rgb'] - g['rgb']).max() <= TOL_RGB
+    assert np.abs(out['alpha'] - g['alpha']).max() <= TOL_ALPHA
+    assert np.abs(out['depth'] - g['depth']).max() <= TOL_DEPTH
+    assert psnr(out['rgb'], g['rgb']) >= 80.0
+    assert np.abs(out['cnl_weight'] - g['cnl_weight']).max() <= TOL_ALPHA
+    assert np.abs(out['weights_on_rays'][:n] - g['weights_on_rays']).max() <= TOL_ALPHA
+    assert np.abs(out['xyz_on_rays'][:n] - g['xyz_on_rays']).max() <= TOL_XYZ
+    assert np.abs(out['offsets'][:n] - g['offsets']).max() <= TOL_XYZ
+    assert np.abs(out['backward_motion_weights'][:n] - g['backward_motion_weights']).max() <= 1e-5
+    assert np.abs(out['rgb_on_rays'][:n] - g['rgb_on_rays']).max() <= 2e-2
+    sel = g['cnl_weight'] > 1e-4
+    same = np.abs(out['cnl_xyz'][sel] - g['cnl_xyz'][sel]).max(axis=-1) < 1e-3
+    assert same.mean() > 0.97
+
+
+def test_lean_path_equals_diagnostic_path(gpu_net, golden_frame):
+    """hnrf_render_rays_fwd (workspace path, 3 outputs) == the 11-output path."""
+    from humannerf_amd import config
+    config.cfg.perturb = 0.
+    try:
+        with torch.no_grad():
+            full = gpu_net(**frame_to_gpu(golden_frame), iter_val=1e7)
+            config.cfg.amd.diagnostics = False
+            lean = gpu_net(**frame_to_gpu(golden_frame), iter_val=1e7)
+    finally:
+        config.cfg.amd.diagnostics = True
+        config.cfg.perturb = 1.0
+    assert set(lean) == {'rgb', 'alpha', 'depth'}
+    for k in lean:
+        assert torch.equal(lean[k], full[k])
+
+
+# ------------------------------------------------------------------ per-kernel vs the oracle
+def test_sample_warp_kernel_edges():
+    """K1 vs oracle incl. points outside the volume, near == far, huge coordinates."""
+    from humannerf_amd import ops
+    from oracle import oracle
+    rs = np.random.RandomState(1)
+    R, S, B, G = 67, 128, 24, 32
+    rays_o = rs.uniform(-1, 1, (R, 3)).astype(np.float32)
+    rays_d = rs.uniform(-1, 1, (R, 3)).astype(np.float32)
+    near = rs.uniform(0.1, 1.0, (R, 1)).astype(np.float32)
+    far = near + rs.uniform(0.0, 3.0, (R, 1)).astype(np.float32)
+    far[0] = near[0]                      # degenerate interval
+    rays_o[1] = [1e6, -1e6, 1e6]          # far outside: every corner zero-padded
+    rays_d[2] = 0
+    Rs = (np.eye(3)[None] + 0.2 * rs.randn(B, 3, 3)).astype(np.float32)
+    Ts = (0.3 * rs.randn(B, 3)).astype(np.float32)
+    vol = rs.uniform(0, 1, (B + 1, G, G, G)).astype(np.float32)
+    vol[:, :, :4] = 0                     # an exactly-empty slab: sum w == 0 samples
+    bmin = np.array([-1.2, -1.4, -0.9], dtype=np.float32)
+    bscale = (2.0 / np.array([2.4, 2.8, 1.8])).astype(np.float32)
+    t_rand = rs.uniform(0, 1, (R, S)).astype(np.float32)
+    T = lambda a: torch.from_numpy(a).to(dev())
+    for tr in (None, t_rand):
+        z, xs, mask, bmw = ops.sample_warp(T(rays_o), T(rays_d), T(near), T(far), None if tr is None else T(tr),
+                                           T(Rs), T(Ts), T(vol), T(bmin), T(bscale), S, want_bmw=True)
+        zo = oracle.z_values(torch.from_numpy(near), torch.from_numpy(far), S, None if tr is None else torch.from_numpy(tr))
+        pts = torch.from_numpy(rays_o)[:, None] + torch.from_numpy(rays_d)[:, None] * zo[:, :, None]
+        xo, mo, wo = oracle.sample_motion_fields(pts.reshape(-1, 3), torch.from_numpy(Rs), torch.from_numpy(Ts),
+                                                 torch.from_numpy(vol), torch.from_numpy(bmin), torch.from_numpy(bscale))
+        assert np.abs(z.cpu().numpy() - zo.numpy()).max() <= 1e-6
+        assert np.abs(bmw.cpu().numpy().reshape(-1, B) - wo.numpy()).max() <= 2e-5
+        assert np.abs(mask.cpu().numpy().reshape(-1) - mo.numpy()).max() <= 1e-4
+        ok = mo.numpy() > 1e-2              # x_skel is ill-conditioned where sum w -> 0
+        err = np.abs(xs.cpu().numpy().reshape(-1, 3) - xo.numpy())
+        big = np.abs(xo.numpy()) < 1e3
+        assert err[ok[:, None] & big].max() <= 2e-4
+        assert torch.isfinite(xs).all() and torch.isfinite(mask).all()
+        assert (mask.cpu().numpy().reshape(R, S)[1] == 0).all()
+        # without the diagnostic output the results are identical
+        z2, xs2, mask2, none = ops.sample_warp(T(rays_o), T(rays_d), T(near), T(far), None if tr is None else T(tr),
+                                               T(Rs), T(Ts), T(vol), T(bmin), T(bscale), S, want_bmw=False)
+        assert none is None and torch.equal(xs, xs2) and torch.equal(mask, mask2)
+
+
+def _mlp_states(rs):
+    from oracle.seeded import default_shapes
+    st = {}
+    for k, s in default_shapes().items():
+        if k.startswith('cnl_mlp') or k.startswith('non_rigid_mlp'):
+            b = np.sqrt(6.0 / sum(s[:2])) * np.sqrt(2) if len(s) == 2 else 0.1
+            st[k] = rs.uniform(-b, b, s).astype(np.float32)
+    return st
+
+
+@pytest.mark.parametrize('P', [1, 31, 128, 1000, 4133])
+def test_canonical_mlp_kernel(P):
+    """K3 vs oracle on ragged sample counts (tail masking, one wave, many blocks)."""
+    from humannerf_amd import ops
+    from oracle import oracle
+    rs = np.random.RandomState(P)
+    st = _mlp_states(rs)
+    xyz = rs.uniform(-1.3, 1.3, (P, 3)).astype(np.float32)
+    idx = [0, 2, 4, 6, 8, 10, 12, 14]
+    ws = [st[f'cnl_mlp.module.pts_linears.{i}.weight'] for i in idx] + [st['cnl_mlp.module.output_linear.0.weight']]
+    bs = [st[f'cnl_mlp.module.pts_linears.{i}.bias'] for i in idx] + [st['cnl_mlp.module.output_linear.0.bias']]
+    T = lambda a: torch.from_numpy(a).to(dev())
+    packed = ops.canonical_pack([T(w) for w in ws], [T(b) for b in bs])
+    raw = ops.canonical(T(xyz), packed).cpu().numpy()
+    ref64 = oracle.canonical_mlp({k: torch.from_numpy(v).double() for k, v in st.items()},
+                                 oracle.fourier_pe(torch.from_numpy(xyz).double(), 10)).numpy()
+    ref32 = oracle.canonical_mlp({k: torch.from_numpy(v) for k, v in st.items()},
+                                 oracle.fourier_pe(torch.from_numpy(xyz), 10)).numpy()
+    scale = max(1.0, np.abs(ref64).max())
+    e_hip, e_cpu = np.abs(raw - ref64).max() / scale, np.abs(ref32 - ref64).max() / scale
+    assert e_hip <= 2e-5, (e_hip, e_cpu)
+    assert e_hip <= 4 * e_cpu + 1e-6, (e_hip, e_cpu)      # as accurate as the CPU fp32 path
+
+
+@pytest.mark.parametrize('P,iter_val', [(1, 1e7), (97, 1e7), (2048, 30000.0), (555, 0.0)])
+def test_nonrigid_mlp_kernel(P, iter_val):
+    from humannerf_amd import ops
+    from oracle import oracle
+    rs = np.random.RandomState(P + 7)
+    st = _mlp_states(rs)
+    st['non_rigid_mlp.module.block_mlps.12.weight'] *= 0.1
+    x = rs.uniform(-1.3, 1.3, (P, 3)).astype(np.float32)
+    cond = rs.uniform(-0.5, 0.5, (69,)).astype(np.float32)
+    if iter_val < 10000:
+        cond = cond * 0
+    hw = oracle.hann_weights(iter_val, 6, 10000, 50000)
+    idx = [0, 2, 4, 6, 8, 10, 12]
+    ws = [st[f'non_rigid_mlp.module.block_mlps.{i}.weight'] for i in idx]
+    bs = [st[f'non_rigid_mlp.module.block_mlps.{i}.bias'] for i in idx]
+    T = lambda a: torch.from_numpy(a).to(dev())
+    packed = ops.nonrigid_pack([T(w) for w in ws], [T(b) for b in bs], T(cond))
+    xyz, ofs = ops.nonrigid(T(x), hw.to(dev()), packed, want_offsets=True)
+    st64 = {k: torch.from_numpy(v).double() for k, v in st.items()}
+    xyz64, ofs64 = oracle.non_rigid_mlp(st64, oracle.hann_pe(torch.from_numpy(x).double(), hw.double()),
+                                        torch.from_numpy(cond).double()[None], torch.from_numpy(x).double())
+    assert np.abs(ofs.cpu().numpy() - ofs64.numpy()).max() <= 2e-6 * max(1.0, float(ofs64.abs().max()) * 10)
+    assert np.abs(xyz.cpu().numpy() - xyz64.numpy()).max() <= 1e-6 + 2e-6 * float(ofs64.abs().max()) * 10
+    xyz2, none = ops.nonrigid(T(x), hw.to(dev()), packed, want_offsets=False)
+    assert none is None and torch.equal(xyz, xyz2)
+
+
+@pytest.mark.parametrize('S', [2, 64, 100, 128, 256, 300])
+def test_composite_kernel(S):
+    from humannerf_amd import ops
+    from oracle import oracle
+    rs = np.random.RandomState(S)
+    R = 37
+    raw = rs.randn(R, S, 4).astype(np.float32) * 3
+    raw[..., 3] = rs.randn(R, S) * 30 + 10
+    raw[3] = -5.0                                  # an empty ray: all weights zero
+    mask = rs.uniform(0, 1.2, (R, S)).astype(np.float32)
+    mask[4] = 0
+    near = rs.uniform(0.5, 1, (R, 1)).astype(np.float32)
+    z = np.sort(near + rs.uniform(0, 3, (R, S)).astype(np.float32), axis=1)
+    rays_d = rs.randn(R, 3).astype(np.float32)
+    xyz = rs.randn(R, S, 3).astype(np.float32)
+    bg = np.array([255., 128., 0.], dtype=np.float32)
+    T = lambda a: torch.from_numpy(a).to(dev())
+    out = ops.composite(T(raw), T(mask), T(z), T(rays_d), T(xyz), T(bg), diagnostics=True)
+    ref = oracle.raw2outputs(*(torch.from_numpy(a).double() for a in (raw, mask, z, rays_d, xyz, bg)))
+    for k in ('rgb', 'alpha', 'depth', 'weights_on_rays', 'rgb_on_rays', 'cnl_weight'):
+        err = np.abs(out[k].cpu().numpy() - ref[k].numpy()).max()
+        assert err <= 3e-6 * max(1.0, float(ref[k].abs().max())), (k, err)
+    w = ref['weights_on_rays'].numpy()
+    srt = np.sort(w, axis=1)
+    clear = (srt[:, -1] - srt[:, -2]) > 1e-6       # unambiguous argmax
+    assert np.array_equal(out['cnl_xyz'].cpu().numpy()[clear], ref['cnl_xyz'].numpy()[clear].astype(np.float32))
+    lean = ops.composite(T(raw), T(mask), T(z), T(rays_d), None, T(bg), diagnostics=False)
+    for k in lean:
+        assert torch.equal(lean[k], out[k])
+
+
+def test_full_size_properties():
+    """BASELINE C2-sized chunk (32768 rays x 128): size-independent properties --
+    permutation equivariance over rays, chunking invariance, empty space -> background."""
+    from humannerf_amd import ops
+    rs = np.random.RandomState(3)
+    st = _mlp_states(rs)
+    T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev())
+    idx = [0, 2, 4, 6, 8, 10, 12, 14]
+    cp = ops.canonical_pack([T(st[f'cnl_mlp.module.pts_linears.{i}.weight']) for i in idx] + [T(st['cnl_mlp.module.output_linear.0.weight'])],
+                            [T(st[f'cnl_mlp.module.pts_linears.{i}.bias']) for i in idx] + [T(st['cnl_mlp.module.output_linear.0.bias'])])
+    idn = [0, 2, 4, 6, 8, 10, 12]
+    cond = T(rs.uniform(-0.3, 0.3, 69).astype(np.float32))
+    npk = ops.nonrigid_pack([T(st[f'non_rigid_mlp.module.block_mlps.{i}.weight']) for i in idn],
+                            [T(st[f'non_rigid_mlp.module.block_mlps.{i}.bias']) for i in idn], cond)
+    from humannerf_amd import scene
+    fr = scene.synthetic_frame(H=512, W=512, focal_at_512=1700.0, ray_stride=2)
+    R = 32768
+    g = {k: T(fr[k]) for k in ('rays', 'near', 'far', 'cnl_bbox_min_xyz', 'cnl_bbox_scale_xyz')}
+    o, d, nr, fa = g['rays'][0][:R].contiguous(), g['rays'][1][:R].contiguous(), g['near'][:R], g['far'][:R]
+    B = 24
+    Rs = T((np.eye(3)[None] + 0.05 * rs.randn(B, 3, 3)).astype(np.float32))
+    Ts = T((0.05 * rs.randn(B, 3)).astype(np.float32))
+    vol = T(fr['motion_weights_priors'])
+    hw = torch.ones(6, device=dev())
+    bg = T(np.array([10., 200., 30.], dtype=np.float32))
+    args = (Rs, Ts, vol, g['cnl_bbox_min_xyz'], g['cnl_bbox_scale_xyz'], hw, npk, cp, bg, 128)
+    a = ops.render_rays(o, d, nr, fa, None, *args)
+    assert all(torch.isfinite(v).all() for v in a.values())
+    assert float(a['alpha'].min()) >= 0 and float(a['alpha'].max()) <= 1 + 1e-5
+    perm = torch.randperm(R, device=dev())
+    b = ops.render_rays(o[perm].contiguous(), d[perm].contiguous(), nr[perm].contiguous(), fa[perm].contiguous(), None, *args)
+    for k in a:
+        assert torch.equal(a[k][perm], b[k])
+    h1 = ops.render_rays(o[:10000].contiguous(), d[:10000].contiguous(), nr[:10000].contiguous(), fa[:10000].contiguous(), None, *args)
+    for k in a:
+        assert torch.equal(a[k][:10000], h1[k])
+    empty = ops.render_rays(o, d, nr, fa, None, Rs, Ts, torch.zeros_like(vol), *args[3:])
+    assert float(empty['alpha'].abs().max()) == 0
+    assert torch.allclose(empty['rgb'], (bg / 255.).expand(R, 3))

@@ -1,0 +1,102 @@
+"""CPU-side checks (no GPU): checkpoint-key contract, C-ABI exports, config
+semantics, scene helpers, loud failure without a GPU."""
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_state_dict_contract():
+    """Key names and shapes of the reference checkpoint."""
+    from humannerf_amd.network import Network
+    from oracle.seeded import default_shapes
+    net = Network()
+    sd = {k: tuple(v.shape) for k, v in net.state_dict().items()}
+    assert sd == default_shapes()
+    assert sum(p.numel() for p in net.parameters()) == 64417381
+    # optimizer routes learning rates by these substrings (optimizer.py:9-34)
+    names = [n for n, _ in net.named_parameters()]
+    for sub in ('mweight_vol_decoder', 'pose_decoder', 'non_rigid_mlp', 'cnl_mlp'):
+        assert any(sub in n for n in names)
+    assert net.deploy_mlps_to_secondary_gpus() is net
+
+
+def test_init_distribution():
+    from humannerf_amd.network import Network
+    net = Network()
+    sd = net.state_dict()
+    assert sd['non_rigid_mlp.module.block_mlps.12.weight'].abs().max() <= 1e-5
+    assert sd['pose_decoder.block_mlps.8.weight'].abs().max() <= 1e-5
+    w = sd['cnl_mlp.module.pts_linears.2.weight']
+    bound = np.sqrt(2.0) * np.sqrt(2.0 / 512) * np.sqrt(3.0)
+    assert w.abs().max() <= bound and w.abs().max() > 0.95 * bound
+    assert sd['cnl_mlp.module.pts_linears.2.bias'].abs().max() == 0
+    k = sd['mweight_vol_decoder.decoder.block_conv.0.weight']
+    assert torch.equal(k[:, :, 0::2, 0::2, 0::2], k[:, :, 1::2, 1::2, 1::2])
+
+
+def test_abi_exports_every_declared_symbol():
+    """libhnrf.so loads and exports exactly what include/hnrf.h declares."""
+    from humannerf_amd import _lib
+    with open(os.path.join(ROOT, 'include', 'hnrf.h')) as f:
+        text = re.sub(r'/\*.*?\*/', '', f.read(), flags=re.S)
+    declared = set(re.findall(r'\b(hnrf_[a-z0-9_]+)\s*\(', text))
+    assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
+    lib = _lib.load()
+    for name in declared:
+        assert hasattr(lib, name)
+    assert lib.hnrf_abi_version() == 1
+    assert lib.hnrf_canonical_packed_bytes(0) > 1 << 20
+    assert lib.hnrf_render_workspace_bytes(4, 128) >= 4 * 128 * 44
+
+
+def test_abi_argument_errors_do_not_need_a_gpu():
+    from humannerf_amd import _lib
+    lib = _lib.load()
+    rc = lib.hnrf_canonical_fwd(None, None, 0, 10, None, None)
+    assert rc == -1 and b'null pointer' in lib.hnrf_last_error()
+    rc = lib.hnrf_canonical_fwd(1, 16, 7, 10, 16, None)
+    assert rc == -2
+
+
+def test_hot_path_fails_loudly_without_gpu():
+    if torch.cuda.is_available():
+        pytest.skip('GPU present')
+    from humannerf_amd import ops, _lib
+    with pytest.raises(_lib.HnrfError):
+        ops.canonical(torch.zeros(8, 3), torch.zeros(16))
+
+
+def test_cfg_semantics():
+    from humannerf_amd.config import get_cfg_defaults
+    c = get_cfg_defaults()
+    assert c.N_samples == 128 and c.chunk == 32768 and c.netchunk_per_gpu == 300000
+    c.merge_from_list(['N_samples', '64', 'non_rigid_motion_mlp.kick_in_iter', '100'])
+    assert c.N_samples == 64 and c.non_rigid_motion_mlp.kick_in_iter == 100
+    with pytest.raises(KeyError):
+        c.merge_from_list(['nope', '1'])
+    c.perturb = 0.
+    assert c.clone().perturb == 0.
+
+
+def test_scene_frame_shapes():
+    from humannerf_amd import scene
+    fr = scene.synthetic_frame(H=64, W=64, focal_at_512=1700.0)
+    assert fr['rays'].shape == (3, 64 * 64, 3)        # every pixel hits the bbox
+    assert fr['near'].shape == (4096, 1) and (fr['far'] > fr['near']).all()
+    p = fr['motion_weights_priors']
+    assert p.shape == (25, 32, 32, 32) and abs(p.sum(0) - 1).max() < 1e-5
+    assert fr['dst_Rs'].shape == (24, 3, 3) and fr['cnl_gtfms'].shape == (24, 4, 4)
+
+
+def test_hann_weights_match_oracle():
+    from humannerf_amd.network import hann_window_weights
+    from oracle import oracle
+    for it in (0, 9999, 10000, 12345.0, 30000, 50000, 1e7):
+        a = hann_window_weights(it, 6, 10000, 50000)
+        b = oracle.hann_weights(it, 6, 10000, 50000)
+        assert torch.equal(a, b)
