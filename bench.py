@@ -1,0 +1,170 @@
+"""bench.py -- headline benchmark of the ray-marching hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W [--mode f32|f16x3]
+
+A "step" is one pass of the hot path over one batch of synthetic input: one
+512x512 frame (262 144 rays that all hit the canonical bbox, 128 samples/ray --
+BASELINE.json configs[1], "387 adventure.yaml freeview render, 512x512, 128
+samples/ray, 1xMI355X") through ``Network.forward`` (eval, perturb = 0, lean
+outputs rgb/alpha/depth).  Inputs and weights are resident in HBM before the
+timed region.  With N > 1 every rank renders its own frames (frame-sharded,
+no data-path collective): weak scaling.  Rank 0 prints ONE JSON line.
+
+Extra objects on that line:
+  roofline     -- dominant kernel (canonical MLP): algorithmic FLOP per launch /
+                  average launch duration measured here with HIP events on the
+                  launch stream, against the MFMA peak of the arithmetic used.
+  cpu_baseline -- the CPU oracle (port of the reference path, parity-pinned by
+                  tests/test_oracle_golden.py) timed on this host on a bounded
+                  sample of the same frame; rank 0, N = 1 only.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+
+H = W = 512
+S = 128
+CNL_MAC_PER_SAMPLE = 492032
+NR_MAC_PER_SAMPLE = 100352           # row a11
+PEAK_TFLOPS = {'f32': 157.3, 'f16x3': 2500.0 / 3.0}   # MI355X_MICROARCH.md; f16x3 issues 3 f16 MFMAs per fp32-equivalent MAC
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=5)
+    ap.add_argument('--warmup', type=int, default=1)
+    ap.add_argument('--mode', default=os.environ.get('HNRF_MLP_MODE', 'f32'), choices=['f32', 'f16x3'])
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-rays', type=int, default=4096)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get('RANK', 0))
+    local_rank = int(os.environ.get('LOCAL_RANK', 0))
+    world = int(os.environ.get('WORLD_SIZE', 1))
+    assert world == args.gpus or world == 1, (world, args.gpus)
+    assert torch.cuda.is_available(), 'bench.py needs an MI355X'
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+
+    from humannerf_amd import scene
+    from humannerf_amd.config import cfg
+    from humannerf_amd.network import Network
+    from oracle.seeded import default_shapes, seeded_state      # weights only (same recipe as the fixtures)
+
+    cfg.perturb, cfg.N_samples, cfg.ignore_non_rigid_motions = 0., S, False
+    cfg.amd.diagnostics = False
+    cfg.amd.mlp_mode = args.mode
+    state = seeded_state(default_shapes(), seed=0)
+    net = Network()
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in state.items()})
+    net = net.to(dev).eval().deploy_mlps_to_secondary_gpus()
+
+    # one synthetic frame per rank (different pose per rank = "independent frames")
+    fr = scene.synthetic_frame(H=H, W=W, focal_at_512=1700.0, pose_seed=rank)
+    keys = ['rays', 'near', 'far', 'dst_Rs', 'dst_Ts', 'cnl_gtfms', 'motion_weights_priors', 'dst_posevec',
+            'cnl_bbox_min_xyz', 'cnl_bbox_scale_xyz', 'bgcolor']
+    data = {k: torch.from_numpy(np.ascontiguousarray(fr[k])).to(dev) for k in keys}
+    R = data['rays'].shape[1]
+    assert R == H * W, R
+
+    def step():
+        with torch.no_grad():
+            return net(**data, iter_val=float(cfg.eval_iter))
+
+    for _ in range(args.warmup):
+        step()
+    net.mlp_event_log = []
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    assert torch.isfinite(out['rgb']).all()
+
+    # roofline of the dominant kernel from the HIP events recorded around every launch
+    ev = net.mlp_event_log
+    net.mlp_event_log = None
+    k_ms = [a.elapsed_time(b) for a, b in ev]
+    launches = len(k_ms)
+    samples_per_launch = R * S * args.steps / launches
+    flop_per_launch = 2.0 * CNL_MAC_PER_SAMPLE * samples_per_launch
+    avg_s = float(np.mean(k_ms)) * 1e-3
+    achieved = flop_per_launch / avg_s / 1e12
+    traffic = None
+    pmc = os.path.join(ROOT, 'profiles', 'r01_pmc_canonical.json')
+    if os.path.isfile(pmc):
+        with open(pmc) as f:
+            traffic = json.load(f).get('hbm_bytes_per_launch')
+    roofline = {'bound': 'mfma', 'kernel': 'canonical_%s_kernel' % args.mode, 'achieved': round(achieved, 2),
+                'peak': PEAK_TFLOPS[args.mode], 'unit': 'TFLOP/s', 'frac': round(achieved / PEAK_TFLOPS[args.mode], 4),
+                'traffic': traffic, 'launches': launches, 'avg_launch_ms': round(avg_s * 1e3, 4),
+                'flop_per_launch': flop_per_launch,
+                'kernel_share_of_step': round(float(np.sum(k_ms)) * 1e-3 / elapsed, 4)}
+
+    result = {
+        'metric': 'rendered rays/sec (128 samples/ray) at 512x512',
+        'value': round(world * R * args.steps / elapsed, 1), 'unit': 'rays/s',
+        'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+        'ms_per_step': round(elapsed / args.steps * 1e3, 3),
+        'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+        'dtype': 'f32' if args.mode == 'f32' else 'f32 (split-f16 x3 MFMA, fp32 accumulate)',
+        'data': 'synthetic',
+        'config': {'workload': 'BASELINE configs[1]: 512x512 freeview frame, 262144 rays x 128 samples, eval, '
+                               'perturb=0, rgb/alpha/depth outputs; seeded random weights of the default architecture',
+                   'rays_per_step_per_gpu': R, 'samples_per_ray': S, 'ray_chunk': int(cfg.chunk),
+                   'mlp_mode': args.mode, 'parallelism': 'frames sharded over %d GPU(s), no collective' % world},
+        'roofline': roofline,
+        'algorithmic_tflops': round(world * R * S * args.steps * 2.0 * (CNL_MAC_PER_SAMPLE + NR_MAC_PER_SAMPLE)
+                                    / elapsed / 1e12, 2),
+    }
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        # bounded sample of the same workload: every (R/cpu_rays)-th ray of the frame
+        from oracle import oracle
+        stride = max(1, R // args.cpu_rays)
+        sub = dict(fr)
+        sub['rays'] = fr['rays'][:, ::stride]
+        sub['near'], sub['far'] = fr['near'][::stride], fr['far'][::stride]
+        n = sub['rays'].shape[1]
+        t0 = time.perf_counter()
+        ref = oracle.render(state, sub, iter_val=float(cfg.eval_iter), N_samples=S)
+        dt = time.perf_counter() - t0
+        err = float((out['rgb'][::stride].cpu() - ref['rgb']).abs().max())
+        result['cpu_baseline'] = {'value': round(n / dt, 1), 'unit': 'rays/s', 'cores': torch.get_num_threads(),
+                                  'kind': 'port', 'host_cpus': os.cpu_count(),
+                                  'sample': '%d rays x %d samples (every %d-th ray of the same frame), torch CPU '
+                                            'fp32 oracle, %.1f s' % (n, S, stride, dt),
+                                  'max_abs_rgb_diff_gpu_vs_cpu': err}
+    if rank == 0:
+        print(json.dumps(result))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

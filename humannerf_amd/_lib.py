@@ -25,7 +25,7 @@ SIGNATURES = {
     'hnrf_canonical_fwd': (_int, [_vp, _vp, _int, _i64, _vp, _vp]),
     'hnrf_composite_fwd': (_int, [_vp] * 6 + [_i64, _int] + [_vp] * 8 + [_vp]),
     'hnrf_render_workspace_bytes': (_sz, [_i64, _int]),
-    'hnrf_render_rays_fwd': (_int, [_vp] * 14 + [_int, _i64, _int, _int, _int, _vp, _sz, _vp, _vp, _vp, _vp]),
+    'hnrf_render_rays_fwd': (_int, [_vp] * 14 + [_int, _i64, _int, _int, _int, _vp, _sz, _vp, _vp, _vp, _vp, _vp, _vp]),
 }
 
 _lib = None
@@ -44,6 +44,14 @@ def load():
         raise HnrfError(
             f'{LIB_PATH} not found: build it with `python -c "import __graft_entry__ as g; g.build()"` '
             f'or `make -C humannerf_amd/csrc`. There is no CPU/PyTorch fallback for the hot path.')
+    # One HIP runtime per process: torch bundles its own libamdhip64 (soname
+    # libamdhip64.so.7).  Import torch FIRST so that libhnrf's NEEDED entry resolves to
+    # that already-loaded copy; loading libhnrf first would pull in /opt/rocm's copy and
+    # torch would then load a second runtime whose allocations ours cannot see.
+    import torch  # noqa: F401
+    tl = os.path.join(os.path.dirname(torch.__file__), 'lib', 'libamdhip64.so')
+    if os.path.isfile(tl):
+        ctypes.CDLL(tl, mode=ctypes.RTLD_GLOBAL)
     lib = ctypes.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)          # AttributeError if a declared symbol is missing

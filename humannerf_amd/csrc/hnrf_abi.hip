@@ -33,7 +33,7 @@ extern "C" int hnrf_render_rays_fwd(const float* rays_o, const float* rays_d, co
                                     const float* hann_w, const void* nr_packed, const void* cnl_packed,
                                     const float* bgcolor, int mode, int64_t R, int S, int B, int G,
                                     void* workspace, size_t workspace_bytes, float* rgb, float* alpha, float* depth,
-                                    void* stream) {
+                                    void* ev_mlp_start, void* ev_mlp_stop, void* stream) {
     HNRF_REQUIRE(workspace && cnl_packed, HNRF_E_ARG, "hnrf_render_rays_fwd: null workspace / canonical weights");
     HNRF_REQUIRE(((uintptr_t)workspace & 255) == 0, HNRF_E_ARG, "hnrf_render_rays_fwd: workspace must be 256-byte aligned");
     HNRF_REQUIRE(workspace_bytes >= hnrf_render_workspace_bytes(R, S), HNRF_E_WORKSPACE,
@@ -55,7 +55,9 @@ extern "C" int hnrf_render_rays_fwd(const float* rays_o, const float* rays_d, co
         if (rc) return rc;
         cnl_in = xyz;
     }
+    if (ev_mlp_start) hipEventRecord((hipEvent_t)ev_mlp_start, (hipStream_t)stream);
     rc = hnrf_canonical_fwd(cnl_in, cnl_packed, mode, (int64_t)P, raw, stream);
+    if (ev_mlp_stop) hipEventRecord((hipEvent_t)ev_mlp_stop, (hipStream_t)stream);
     if (rc) return rc;
     return hnrf_composite_fwd(raw, mask, z_vals, rays_d, nullptr, bgcolor, R, S, rgb, alpha, depth, nullptr, nullptr,
                               nullptr, nullptr, nullptr, stream);

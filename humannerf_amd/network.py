@@ -254,6 +254,10 @@ class Network(nn.Module):
         self._cnl_pack = None     # (key, packed image)
         self._nr_pack_buf = None
         self._vol_cache = None    # (key, priors, volume)
+        self._workspace = None
+        # set to a list to collect (start, stop) torch.cuda.Event pairs recorded around
+        # every canonical-MLP launch of the lean path (bench.py roofline)
+        self.mlp_event_log = None
 
     # reference API ---------------------------------------------------------
     def deploy_mlps_to_secondary_gpus(self):
@@ -366,8 +370,16 @@ class Network(nn.Module):
                      hann_w, nr_packed, cnl_packed, bg, S, mode, diag):
         """network.py:474-602 for one ray chunk."""
         if not diag:
+            need = ops.render_workspace_bytes(rays_o.shape[0], S) // 4 + 64
+            if self._workspace is None or self._workspace.numel() < need or self._workspace.device != rays_o.device:
+                self._workspace = torch.empty(need, device=rays_o.device)
+            events = None
+            if self.mlp_event_log is not None:
+                events = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                self.mlp_event_log.append(events)
             return ops.render_rays(rays_o, rays_d, near, far, t_rand, motion_Rs, motion_Ts, vol, bbox_min,
-                                   bbox_scale, hann_w, nr_packed, cnl_packed, bg, S, mode)
+                                   bbox_scale, hann_w, nr_packed, cnl_packed, bg, S, mode,
+                                   workspace=self._workspace, mlp_events=events)
         z, x_skel, mask, bmw = ops.sample_warp(rays_o, rays_d, near, far, t_rand, motion_Rs, motion_Ts, vol,
                                                bbox_min, bbox_scale, S, want_bmw=True)
         if nr_packed is not None:

@@ -152,9 +152,12 @@ def render_workspace_bytes(R, S):
 
 
 def render_rays(rays_o, rays_d, near, far, t_rand, motion_Rs, motion_Ts, vol, bbox_min, bbox_scale,
-                hann_w, nr_packed, cnl_packed, bgcolor, n_samples, mode='f32', workspace=None, out=None):
+                hann_w, nr_packed, cnl_packed, bgcolor, n_samples, mode='f32', workspace=None, out=None,
+                mlp_events=None):
     """The whole path for one ray chunk (network.py:474-602) with only the
-    rgb/alpha/depth outputs; intermediates live in ``workspace``."""
+    rgb/alpha/depth outputs; intermediates live in ``workspace``.  ``mlp_events``:
+    optional pair of torch.cuda.Event(enable_timing=True), recorded around the
+    canonical-MLP launch."""
     lib = _lib.load()
     near, far = near.reshape(-1), far.reshape(-1)
     _chk(rays_o, rays_d, near, far, t_rand, motion_Rs, motion_Ts, vol, bbox_min, bbox_scale, hann_w,
@@ -168,11 +171,18 @@ def render_rays(rays_o, rays_d, near, far, t_rand, motion_Rs, motion_Ts, vol, bb
     if out is None:
         out = {'rgb': torch.empty(R, 3, device=dev), 'alpha': torch.empty(R, device=dev),
                'depth': torch.empty(R, device=dev)}
+    ev = (0, 0)
+    if mlp_events is not None:
+        for e in mlp_events:
+            if not e.cuda_event:
+                e.record()            # forces creation of the hipEvent_t
+        ev = (mlp_events[0].cuda_event, mlp_events[1].cuda_event)
     _lib.check(lib.hnrf_render_rays_fwd(_ptr(rays_o), _ptr(rays_d), _ptr(near), _ptr(far), _ptr(t_rand),
                                         _ptr(motion_Rs), _ptr(motion_Ts), _ptr(vol), _ptr(bbox_min),
                                         _ptr(bbox_scale), _ptr(hann_w), _ptr(nr_packed), _ptr(cnl_packed),
                                         _ptr(bgcolor), MLP_MODES[mode], R, S, motion_Rs.shape[0], vol.shape[-1],
                                         _ptr(workspace), workspace.numel() * workspace.element_size(),
-                                        _ptr(out['rgb']), _ptr(out['alpha']), _ptr(out['depth']), _stream()),
+                                        _ptr(out['rgb']), _ptr(out['alpha']), _ptr(out['depth']),
+                                        ev[0], ev[1], _stream()),
                'hnrf_render_rays_fwd')
     return out

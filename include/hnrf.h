@@ -111,7 +111,10 @@ int hnrf_composite_fwd(const float* raw, const float* fg_mask, const float* z_va
  * (hnrf_render_workspace_bytes(R,S) bytes, 256-byte aligned).
  * nr_packed == NULL means cfg.ignore_non_rigid_motions (network.py:264,276-277).
  * Only rgb/alpha/depth are written (the trainer and the image writers read
- * nothing else: trainer.py:121, run.py:130). */
+ * nothing else: trainer.py:121, run.py:130).
+ * ev_mlp_start / ev_mlp_stop: optional hipEvent_t (as void*, may be NULL) recorded
+ * on `stream` right before / after the canonical-MLP launch, so a caller can time
+ * the dominant kernel without a profiler (bench.py roofline). */
 size_t hnrf_render_workspace_bytes(int64_t R, int S);
 int hnrf_render_rays_fwd(const float* rays_o, const float* rays_d,
                          const float* near, const float* far, const float* t_rand,
@@ -121,7 +124,8 @@ int hnrf_render_rays_fwd(const float* rays_o, const float* rays_d,
                          const float* bgcolor, int mode,
                          int64_t R, int S, int B, int G,
                          void* workspace, size_t workspace_bytes,
-                         float* rgb, float* alpha, float* depth, void* stream);
+                         float* rgb, float* alpha, float* depth,
+                         void* ev_mlp_start, void* ev_mlp_stop, void* stream);
 
 #ifdef __cplusplus
 }
