@@ -28,4 +28,13 @@ static inline int check_launch(const char* what) {
 
 constexpr int kWave = 64;
 
+// HNRF_MLP_F16X3 back end (hnrf_mlp_f16.hip)
+size_t canonical16_bytes();
+size_t nonrigid16_bytes();
+int canonical16_pack(const float* const* w, const float* const* b, void* packed, hipStream_t st);
+int nonrigid16_pack(const float* const* w, const float* const* b, const float* cond, void* packed, hipStream_t st);
+int canonical16_fwd(const float* xyz, const void* packed, int64_t P, float* raw, hipStream_t st);
+int nonrigid16_fwd(const float* x_skel, const float* hann_w, const void* packed, int64_t P, float* xyz,
+                   float* offsets, hipStream_t st);
+
 }  // namespace hnrf

@@ -304,19 +304,23 @@ static int launch_pack(const PackLayer& d, const float* cond, float* packed, hip
 using namespace hnrf;
 
 extern "C" size_t hnrf_canonical_packed_bytes(int mode) {
+    if (mode == HNRF_MLP_F16X3) return canonical16_bytes();
     return mode == HNRF_MLP_F32 ? (size_t)CNL_FLOATS * sizeof(float) : 0;
 }
 extern "C" size_t hnrf_nonrigid_packed_bytes(int mode) {
+    if (mode == HNRF_MLP_F16X3) return nonrigid16_bytes();
     return mode == HNRF_MLP_F32 ? (size_t)NR_FLOATS * sizeof(float) : 0;
 }
 
 extern "C" int hnrf_canonical_pack(const float* const* weights, const float* const* biases, int mode, void* packed,
                                    void* stream) {
     HNRF_REQUIRE(weights && biases && packed, HNRF_E_ARG, "hnrf_canonical_pack: null pointer");
-    HNRF_REQUIRE(mode == HNRF_MLP_F32, HNRF_E_UNSUPPORTED, "hnrf_canonical_pack: mode %d not built", mode);
+    HNRF_REQUIRE(mode == HNRF_MLP_F32 || mode == HNRF_MLP_F16X3, HNRF_E_UNSUPPORTED,
+                 "hnrf_canonical_pack: mode %d not built", mode);
     for (int i = 0; i < 9; ++i)
         HNRF_REQUIRE(weights[i] && biases[i], HNRF_E_ARG, "hnrf_canonical_pack: null layer %d", i);
     hipStream_t st = (hipStream_t)stream;
+    if (mode == HNRF_MLP_F16X3) return canonical16_pack(weights, biases, packed, st);
     float* out = (float*)packed;
     int rc;
     // zero the prefetch over-run pad
@@ -350,10 +354,12 @@ extern "C" int hnrf_canonical_pack(const float* const* weights, const float* con
 extern "C" int hnrf_nonrigid_pack(const float* const* weights, const float* const* biases, const float* cond,
                                   int mode, void* packed, void* stream) {
     HNRF_REQUIRE(weights && biases && cond && packed, HNRF_E_ARG, "hnrf_nonrigid_pack: null pointer");
-    HNRF_REQUIRE(mode == HNRF_MLP_F32, HNRF_E_UNSUPPORTED, "hnrf_nonrigid_pack: mode %d not built", mode);
+    HNRF_REQUIRE(mode == HNRF_MLP_F32 || mode == HNRF_MLP_F16X3, HNRF_E_UNSUPPORTED,
+                 "hnrf_nonrigid_pack: mode %d not built", mode);
     for (int i = 0; i < 7; ++i)
         HNRF_REQUIRE(weights[i] && biases[i], HNRF_E_ARG, "hnrf_nonrigid_pack: null layer %d", i);
     hipStream_t st = (hipStream_t)stream;
+    if (mode == HNRF_MLP_F16X3) return nonrigid16_pack(weights, biases, cond, packed, st);
     float* out = (float*)packed;
     int rc;
     if (hipMemsetAsync(out + NR_W_END, 0, PF * 256 * sizeof(float), st) != hipSuccess) {
@@ -380,11 +386,13 @@ extern "C" int hnrf_nonrigid_pack(const float* const* weights, const float* cons
 extern "C" int hnrf_canonical_fwd(const float* xyz, const void* packed, int mode, int64_t P, float* raw,
                                   void* stream) {
     HNRF_REQUIRE(xyz && packed && raw, HNRF_E_ARG, "hnrf_canonical_fwd: null pointer");
-    HNRF_REQUIRE(mode == HNRF_MLP_F32, HNRF_E_UNSUPPORTED, "hnrf_canonical_fwd: mode %d not built", mode);
+    HNRF_REQUIRE(mode == HNRF_MLP_F32 || mode == HNRF_MLP_F16X3, HNRF_E_UNSUPPORTED,
+                 "hnrf_canonical_fwd: mode %d not built", mode);
     HNRF_REQUIRE(P >= 0 && (P + 127) / 128 < 2147483647LL, HNRF_E_ARG, "hnrf_canonical_fwd: bad P=%lld", (long long)P);
     HNRF_REQUIRE((((uintptr_t)packed | (uintptr_t)raw) & 15) == 0, HNRF_E_ARG,
                  "hnrf_canonical_fwd: packed/raw must be 16-byte aligned");
     if (P == 0) return HNRF_OK;
+    if (mode == HNRF_MLP_F16X3) return canonical16_fwd(xyz, packed, P, raw, (hipStream_t)stream);
     hipLaunchKernelGGL(canonical_f32_kernel, dim3((unsigned)((P + 127) / 128)), dim3(256), 0, (hipStream_t)stream,
                        xyz, (const float*)packed, P, (float4*)raw);
     return check_launch("hnrf_canonical_fwd");
@@ -393,10 +401,12 @@ extern "C" int hnrf_canonical_fwd(const float* xyz, const void* packed, int mode
 extern "C" int hnrf_nonrigid_fwd(const float* x_skel, const float* hann_w, const void* packed, int mode, int64_t P,
                                  float* xyz, float* offsets, void* stream) {
     HNRF_REQUIRE(x_skel && hann_w && packed && xyz, HNRF_E_ARG, "hnrf_nonrigid_fwd: null pointer");
-    HNRF_REQUIRE(mode == HNRF_MLP_F32, HNRF_E_UNSUPPORTED, "hnrf_nonrigid_fwd: mode %d not built", mode);
+    HNRF_REQUIRE(mode == HNRF_MLP_F32 || mode == HNRF_MLP_F16X3, HNRF_E_UNSUPPORTED,
+                 "hnrf_nonrigid_fwd: mode %d not built", mode);
     HNRF_REQUIRE(P >= 0 && (P + 127) / 128 < 2147483647LL, HNRF_E_ARG, "hnrf_nonrigid_fwd: bad P=%lld", (long long)P);
     HNRF_REQUIRE(((uintptr_t)packed & 15) == 0, HNRF_E_ARG, "hnrf_nonrigid_fwd: packed must be 16-byte aligned");
     if (P == 0) return HNRF_OK;
+    if (mode == HNRF_MLP_F16X3) return nonrigid16_fwd(x_skel, hann_w, packed, P, xyz, offsets, (hipStream_t)stream);
     hipLaunchKernelGGL(nonrigid_f32_kernel, dim3((unsigned)((P + 127) / 128)), dim3(256), 0, (hipStream_t)stream,
                        x_skel, hann_w, (const float*)packed, P, xyz, offsets);
     return check_launch("hnrf_nonrigid_fwd");

@@ -74,9 +74,8 @@ def nonrigid_pack(weights, biases, cond, mode='f32', out=None):
             raise _lib.HnrfError(f'non-rigid MLP layer shape {tuple(w.shape)} != {s}: only the default '
                                  f'architecture (default.yaml:142-165) is built')
     nbytes = lib.hnrf_nonrigid_packed_bytes(m)
-    if out is None:
-        out = torch.empty(nbytes // 4, device=cond.device)
-    assert out.numel() * 4 >= nbytes
+    if out is None or out.numel() * 4 < nbytes:
+        out = torch.empty((nbytes + 3) // 4, device=cond.device)
     _lib.check(lib.hnrf_nonrigid_pack(_ptr_array(weights), _ptr_array(biases), _ptr(cond), m, _ptr(out),
                                       _stream()), 'hnrf_nonrigid_pack')
     return out
@@ -106,9 +105,8 @@ def canonical_pack(weights, biases, mode='f32', out=None):
             raise _lib.HnrfError(f'canonical MLP layer shape {tuple(w.shape)} != {s}: only the default '
                                  f'architecture (default.yaml:51-57) is built')
     nbytes = lib.hnrf_canonical_packed_bytes(m)
-    if out is None:
-        out = torch.empty(nbytes // 4, device=weights[0].device)
-    assert out.numel() * 4 >= nbytes
+    if out is None or out.numel() * 4 < nbytes:
+        out = torch.empty((nbytes + 3) // 4, device=weights[0].device)
     _lib.check(lib.hnrf_canonical_pack(_ptr_array(weights), _ptr_array(biases), m, _ptr(out), _stream()),
                'hnrf_canonical_pack')
     return out

@@ -51,9 +51,11 @@ def frame_to_gpu(fr):
 CASES = ['eval_s128', 'eval_s64', 'tpose_s128', 'iter0_s128', 'iter5000_s128', 'iter30000_s128', 'perturb_s128']
 
 
+@pytest.mark.parametrize('mode', ['f32', 'f16x3'])
 @pytest.mark.parametrize('case', CASES)
-def test_network_matches_reference_golden(case, gpu_net, golden_frame, golden_dir):
+def test_network_matches_reference_golden(case, mode, gpu_net, golden_frame, golden_dir):
     from humannerf_amd.config import cfg
+    cfg.amd.mlp_mode = mode
     with open(os.path.join(golden_dir, 'meta.json')) as f:
         m = json.load(f)[case]
     g = np.load(os.path.join(golden_dir, case + '.npz'))
@@ -67,7 +69,10 @@ def test_network_matches_reference_golden(case, gpu_net, golden_frame, golden_di
             out = gpu_net(**frame_to_gpu(golden_frame), iter_val=m['iter_val'], **kw)
     finally:
         cfg.N_samples, cfg.perturb, cfg.ignore_non_rigid_motions = 128, 1.0, False
+        cfg.amd.mlp_mode = 'f32'
     out = {k: v.cpu().numpy() for k, v in out.items()}
+    print(case, mode, 'max err rgb %.2e alpha %.2e depth %.2e' % (np.abs(out['rgb'] - g['rgb']).max(),
+          np.abs(out['alpha'] - g['alpha']).max(), np.abs(out['depth'] - g['depth']).max()))
     assert set(out) == {'rgb', 'alpha', 'depth', 'weights_on_rays', 'xyz_on_rays', 'rgb_on_rays', 'cnl_xyz',
                         'cnl_rgb', 'cnl_weight', 'backward_motion_weights', 'offsets'}
     n = m['keep_rays']
@@ -158,8 +163,9 @@ def _mlp_states(rs):
     return st
 
 
+@pytest.mark.parametrize('mode', ['f32', 'f16x3'])
 @pytest.mark.parametrize('P', [1, 31, 128, 1000, 4133])
-def test_canonical_mlp_kernel(P):
+def test_canonical_mlp_kernel(P, mode):
     """K3 vs oracle on ragged sample counts (tail masking, one wave, many blocks)."""
     from humannerf_amd import ops
     from oracle import oracle
@@ -170,20 +176,22 @@ def test_canonical_mlp_kernel(P):
     ws = [st[f'cnl_mlp.module.pts_linears.{i}.weight'] for i in idx] + [st['cnl_mlp.module.output_linear.0.weight']]
     bs = [st[f'cnl_mlp.module.pts_linears.{i}.bias'] for i in idx] + [st['cnl_mlp.module.output_linear.0.bias']]
     T = lambda a: torch.from_numpy(a).to(dev())
-    packed = ops.canonical_pack([T(w) for w in ws], [T(b) for b in bs])
-    raw = ops.canonical(T(xyz), packed).cpu().numpy()
+    packed = ops.canonical_pack([T(w) for w in ws], [T(b) for b in bs], mode)
+    raw = ops.canonical(T(xyz), packed, mode).cpu().numpy()
     ref64 = oracle.canonical_mlp({k: torch.from_numpy(v).double() for k, v in st.items()},
                                  oracle.fourier_pe(torch.from_numpy(xyz).double(), 10)).numpy()
     ref32 = oracle.canonical_mlp({k: torch.from_numpy(v) for k, v in st.items()},
                                  oracle.fourier_pe(torch.from_numpy(xyz), 10)).numpy()
     scale = max(1.0, np.abs(ref64).max())
     e_hip, e_cpu = np.abs(raw - ref64).max() / scale, np.abs(ref32 - ref64).max() / scale
+    print('canonical', mode, P, 'rel err hip %.2e cpu-fp32 %.2e' % (e_hip, e_cpu))
     assert e_hip <= 2e-5, (e_hip, e_cpu)
     assert e_hip <= 4 * e_cpu + 1e-6, (e_hip, e_cpu)      # as accurate as the CPU fp32 path
 
 
+@pytest.mark.parametrize('mode', ['f32', 'f16x3'])
 @pytest.mark.parametrize('P,iter_val', [(1, 1e7), (97, 1e7), (2048, 30000.0), (555, 0.0)])
-def test_nonrigid_mlp_kernel(P, iter_val):
+def test_nonrigid_mlp_kernel(P, iter_val, mode):
     from humannerf_amd import ops
     from oracle import oracle
     rs = np.random.RandomState(P + 7)
@@ -198,14 +206,14 @@ def test_nonrigid_mlp_kernel(P, iter_val):
     ws = [st[f'non_rigid_mlp.module.block_mlps.{i}.weight'] for i in idx]
     bs = [st[f'non_rigid_mlp.module.block_mlps.{i}.bias'] for i in idx]
     T = lambda a: torch.from_numpy(a).to(dev())
-    packed = ops.nonrigid_pack([T(w) for w in ws], [T(b) for b in bs], T(cond))
-    xyz, ofs = ops.nonrigid(T(x), hw.to(dev()), packed, want_offsets=True)
+    packed = ops.nonrigid_pack([T(w) for w in ws], [T(b) for b in bs], T(cond), mode)
+    xyz, ofs = ops.nonrigid(T(x), hw.to(dev()), packed, mode, want_offsets=True)
     st64 = {k: torch.from_numpy(v).double() for k, v in st.items()}
     xyz64, ofs64 = oracle.non_rigid_mlp(st64, oracle.hann_pe(torch.from_numpy(x).double(), hw.double()),
                                         torch.from_numpy(cond).double()[None], torch.from_numpy(x).double())
     assert np.abs(ofs.cpu().numpy() - ofs64.numpy()).max() <= 2e-6 * max(1.0, float(ofs64.abs().max()) * 10)
     assert np.abs(xyz.cpu().numpy() - xyz64.numpy()).max() <= 1e-6 + 2e-6 * float(ofs64.abs().max()) * 10
-    xyz2, none = ops.nonrigid(T(x), hw.to(dev()), packed, want_offsets=False)
+    xyz2, none = ops.nonrigid(T(x), hw.to(dev()), packed, mode, want_offsets=False)
     assert none is None and torch.equal(xyz, xyz2)
 
 
