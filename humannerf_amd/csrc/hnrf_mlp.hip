@@ -27,6 +27,7 @@
 // cycles per 32 samples = 596 K SIMD-cycles; 592 384 algorithmic MAC per sample
 // (99.4 % of the issued MACs are algorithmic; the rest is K/N padding).
 #include "hnrf_common.h"
+#include "hnrf_sincos.h"
 
 namespace hnrf {
 
@@ -196,11 +197,14 @@ __global__ __launch_bounds__(256) void canonical_f32_kernel(const float* __restr
 
     // positional encoding in B-operand order (see pe_col): 32 K-steps
     float pe[32];
+    {
+        OctavePhase ph[3] = {OctavePhase(x[0]), OctavePhase(x[1]), OctavePhase(x[2])};
 #pragma unroll
-    for (int j = 0; j < 30; ++j) {
-        float sv, cv;
-        sincosf(x[j % 3] * (float)(1 << (j / 3)), &sv, &cv);
-        pe[j] = h ? cv : sv;
+        for (int j = 0; j < 30; ++j) {
+            float sv, cv;
+            ph[j % 3].next(sv, cv);
+            pe[j] = h ? cv : sv;
+        }
     }
     pe[30] = h ? x[1] : x[0];
     pe[31] = h ? 0.f : x[2];
@@ -250,11 +254,14 @@ __global__ __launch_bounds__(256) void nonrigid_f32_kernel(const float* __restri
     const float x[3] = {x_skel[sidx * 3 + 0], x_skel[sidx * 3 + 1], x_skel[sidx * 3 + 2]};
 
     float pe[20];
+    {
+        OctavePhase ph[3] = {OctavePhase(x[0]), OctavePhase(x[1]), OctavePhase(x[2])};
 #pragma unroll
-    for (int j = 0; j < 18; ++j) {
-        float sv, cv;
-        sincosf(x[j % 3] * (float)(1 << (j / 3)), &sv, &cv);
-        pe[j] = hann_w[j / 3] * (h ? cv : sv);
+        for (int j = 0; j < 18; ++j) {
+            float sv, cv;
+            ph[j % 3].next(sv, cv);
+            pe[j] = hann_w[j / 3] * (h ? cv : sv);
+        }
     }
     pe[18] = 0.f;
     pe[19] = 0.f;
