@@ -1,0 +1,300 @@
+// Backward kernels of the per-sample stages around the MLPs (training):
+//   K4' composite backward   -- d(rgb, alpha, depth) -> d raw, d fg_mask
+//   PE' positional-encoding backward -- d PE -> d xyz
+//   K1' LBS-warp backward    -- d x_skel, d fg_mask -> d volume (atomics), d motion_Rs, d motion_Ts
+// They restate what torch.autograd derives for the reference's forward ops
+// (network.py:355-388, fourier.py / hannw_fourier.py embed, network.py:392-444 incl. the
+// grid_sample gradient w.r.t. both the volume and the sampling position).  The MLP GEMM
+// backward itself (dW = dZ^T X, dX = dZ W) runs as plain library GEMMs on the activation
+// matrices saved by hnrf_*_fwd_train.
+#include "hnrf_common.h"
+
+namespace hnrf {
+
+// ----------------------------------------------------------------------------- K4'
+// One wave per ray, SPL samples per lane (same layout as composite_kernel).
+//   w_i = a_i T_i,  T_i = prod_{j<i} t_j,  t_j = 1 - a_j + 1e-10
+//   out = sum w_i c_i + (1 - sum w_i) bg,  depth = sum w_i z_i,  acc = sum w_i
+//   dL/dw_i = g_rgb.(c_i - bg) + g_acc + g_depth z_i
+//   dL/da_i = T_i dL/dw_i - (sum_{j>i} dL/dw_j w_j) / t_i
+template <int SPL>
+__global__ __launch_bounds__(256) void composite_bwd_kernel(
+    const float4* __restrict__ raw, const float* __restrict__ fg_mask, const float* __restrict__ z_vals,
+    const float* __restrict__ rays_d, const float* __restrict__ bgcolor, const float* __restrict__ g_rgb,
+    const float* __restrict__ g_alpha, const float* __restrict__ g_depth, int64_t R, int S,
+    float4* __restrict__ d_raw, float* __restrict__ d_mask) {
+    const int lane = threadIdx.x & 63;
+    const int64_t ray = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (ray >= R) return;
+    const float dx = rays_d[ray * 3 + 0], dy = rays_d[ray * 3 + 1], dz = rays_d[ray * 3 + 2];
+    const float dnorm = sqrtf(dx * dx + dy * dy + dz * dz);
+    const int64_t base = ray * S;
+    const float bg0 = bgcolor[0] / 255.f, bg1 = bgcolor[1] / 255.f, bg2 = bgcolor[2] / 255.f;
+    const float gr = g_rgb[ray * 3 + 0], gg = g_rgb[ray * 3 + 1], gb = g_rgb[ray * 3 + 2];
+    const float ga = g_alpha ? g_alpha[ray] : 0.f, gd = g_depth ? g_depth[ray] : 0.f;
+
+    float zv[SPL], al[SPL], ee[SPL], dl[SPL], cr[SPL], cg[SPL], cb[SPL], mk[SPL];
+    float4 rw[SPL];
+#pragma unroll
+    for (int i = 0; i < SPL; ++i) {
+        const int s = lane * SPL + i;
+        const int sc = s < S ? s : S - 1;
+        rw[i] = raw[base + sc];
+        mk[i] = s < S ? fg_mask[base + sc] : 0.f;
+        zv[i] = z_vals[base + sc];
+    }
+    const float znext_lane = __shfl_down(zv[0], 1, 64);
+    float tl = 1.f;
+#pragma unroll
+    for (int i = 0; i < SPL; ++i) {
+        const int s = lane * SPL + i;
+        const float zn = (i + 1 < SPL) ? zv[(i + 1 < SPL) ? i + 1 : i] : znext_lane;
+        float dist = (s >= S - 1) ? 1e10f : (zn - zv[i]);
+        dist *= dnorm;
+        dl[i] = dist;
+        const float sig = fmaxf(rw[i].w, 0.f);
+        ee[i] = expf(-sig * dist);
+        al[i] = (1.0f - ee[i]) * mk[i];
+        cr[i] = 1.0f / (1.0f + expf(-rw[i].x));
+        cg[i] = 1.0f / (1.0f + expf(-rw[i].y));
+        cb[i] = 1.0f / (1.0f + expf(-rw[i].z));
+        if (s < S) tl *= (1.0f - al[i] + 1e-10f);
+    }
+    float incl = tl;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const float o = __shfl_up(incl, off, 64);
+        if (lane >= off) incl *= o;
+    }
+    float T = __shfl_up(incl, 1, 64);
+    if (lane == 0) T = 1.f;
+    // per-sample T, w, dL/dw and the lane-local sum of dL/dw * w
+    float Ti[SPL], gw[SPL], wv[SPL];
+    float loc = 0.f;
+#pragma unroll
+    for (int i = 0; i < SPL; ++i) {
+        const int s = lane * SPL + i;
+        Ti[i] = T;
+        wv[i] = al[i] * T;
+        T *= (1.0f - al[i] + 1e-10f);
+        gw[i] = gr * (cr[i] - bg0) + gg * (cg[i] - bg1) + gb * (cb[i] - bg2) + ga + gd * zv[i];
+        if (s >= S) { gw[i] = 0.f; wv[i] = 0.f; }
+        loc += gw[i] * wv[i];
+    }
+    // exclusive suffix sum over lanes of `loc`
+    float suf = loc;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const float o = __shfl_down(suf, off, 64);
+        if (lane + off < 64) suf += o;
+    }
+    float after = suf - loc;   // sum over later lanes
+#pragma unroll
+    for (int i = SPL - 1; i >= 0; --i) {
+        const int s = lane * SPL + i;
+        if (s < S) {
+            const float t = 1.0f - al[i] + 1e-10f;
+            const float da = Ti[i] * gw[i] - after / t;
+            after += gw[i] * wv[i];
+            const float dsig = (rw[i].w > 0.f) ? da * mk[i] * dl[i] * ee[i] : 0.f;
+            float4 o;
+            o.x = wv[i] * gr * cr[i] * (1.0f - cr[i]);
+            o.y = wv[i] * gg * cg[i] * (1.0f - cg[i]);
+            o.z = wv[i] * gb * cb[i] * (1.0f - cb[i]);
+            o.w = dsig;
+            d_raw[base + s] = o;
+            d_mask[base + s] = da * (1.0f - ee[i]);
+        }
+    }
+}
+
+// ----------------------------------------------------------------------------- PE'
+// d xyz[p][ax] (+)= [include_input] g[p][ax] + sum_k w_k 2^k (cos(2^k x) g_sin - sin(2^k x) g_cos)
+// g layout = the embedders' output order; NB bands; hann == nullptr -> all weights 1.
+__global__ void pe_bwd_kernel(const float* __restrict__ x, const float* __restrict__ g, const float* __restrict__ hann,
+                              int64_t P, int NB, int include_input, int accumulate, float* __restrict__ dx) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= P * 3) return;
+    const int64_t p = i / 3;
+    const int ax = (int)(i - p * 3);
+    const int C = (include_input ? 3 : 0) + 6 * NB;
+    const float* gp = g + p * C;
+    const float xv = x[i];
+    float acc = include_input ? gp[ax] : 0.f;
+    const int o0 = include_input ? 3 : 0;
+    for (int k = 0; k < NB; ++k) {
+        const float f = (float)(1 << k);
+        float sv, cv;
+        sincosf(xv * f, &sv, &cv);
+        const float w = hann ? hann[k] : 1.0f;
+        acc += w * f * (cv * gp[o0 + 6 * k + ax] - sv * gp[o0 + 6 * k + 3 + ax]);
+    }
+    dx[i] = accumulate ? dx[i] + acc : acc;
+}
+
+// ----------------------------------------------------------------------------- K1'
+// grid = (sample blocks, bones).  x_skel = A / den, A = sum_b w_b pos_b, den = max(mask, 1e-4),
+// mask = sum_b w_b (both saved by the forward), so bone b only needs its own w_b, pos_b:
+//   dL/dw_b   = gA . pos_b + g_ws,   gA = g_x / den,
+//   g_ws      = g_mask + [mask >= 1e-4] * (-(g_x . x_skel) / den)
+//   dL/dpos_b = w_b gA + dL/dw_b * grad_pos trilinear(vol_b)        (grid_sample's grid gradient)
+//   dL/dvol_b[corner] += dL/dw_b * corner weight                     (global float atomics)
+//   dL/dR_b += dL/dpos_b (x) x,   dL/dT_b += dL/dpos_b               (block reduction, 12 atomics)
+__global__ __launch_bounds__(256) void sample_warp_bwd_kernel(
+    const float* __restrict__ rays_o, const float* __restrict__ rays_d, const float* __restrict__ z_vals,
+    const float* __restrict__ Rs, const float* __restrict__ Ts, const float* __restrict__ vol,
+    const float* __restrict__ bbox_min, const float* __restrict__ bbox_scale, const float* __restrict__ x_skel,
+    const float* __restrict__ fg_mask, const float* __restrict__ g_x, const float* __restrict__ g_mask, int64_t P,
+    int S, int G, float* __restrict__ d_vol, float* __restrict__ d_Rs, float* __restrict__ d_Ts) {
+    const int b = blockIdx.y;
+    const float* Rb = Rs + b * 9;
+    const float* Tb = Ts + b * 3;
+    const float R0 = Rb[0], R1 = Rb[1], R2 = Rb[2], R3 = Rb[3], R4 = Rb[4], R5 = Rb[5], R6 = Rb[6], R7 = Rb[7],
+                R8 = Rb[8];
+    const float T0 = Tb[0], T1 = Tb[1], T2 = Tb[2];
+    const float bmx = bbox_min[0], bmy = bbox_min[1], bmz = bbox_min[2];
+    const float bsx = bbox_scale[0], bsy = bbox_scale[1], bsz = bbox_scale[2];
+    const float gm1 = (float)(G - 1);
+    const int GG = G * G;
+    const float* vb = vol + (size_t)b * G * GG;
+    float* dvb = d_vol + (size_t)b * G * GG;
+
+    float acc[12];
+#pragma unroll
+    for (int i = 0; i < 12; ++i) acc[i] = 0.f;
+
+    for (int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x; p < P; p += (int64_t)gridDim.x * 256) {
+        const int64_t r = p / S;
+        const float z = z_vals[p];
+        const float px = rays_o[r * 3 + 0] + rays_d[r * 3 + 0] * z;
+        const float py = rays_o[r * 3 + 1] + rays_d[r * 3 + 1] * z;
+        const float pz = rays_o[r * 3 + 2] + rays_d[r * 3 + 2] * z;
+        const float m = fg_mask[p];
+        const float den = fmaxf(m, 0.0001f);
+        const float gx0 = g_x[p * 3 + 0], gx1 = g_x[p * 3 + 1], gx2 = g_x[p * 3 + 2];
+        const float gA0 = gx0 / den, gA1 = gx1 / den, gA2 = gx2 / den;
+        float gws = g_mask[p];
+        if (m >= 0.0001f) gws -= (gx0 * x_skel[p * 3 + 0] + gx1 * x_skel[p * 3 + 1] + gx2 * x_skel[p * 3 + 2]) / den;
+
+        const float qx = R0 * px + R1 * py + R2 * pz + T0;
+        const float qy = R3 * px + R4 * py + R5 * pz + T1;
+        const float qz = R6 * px + R7 * py + R8 * pz + T2;
+        const float ix = (((qx - bmx) * bsx - 1.0f) + 1.0f) * 0.5f * gm1;
+        const float iy = (((qy - bmy) * bsy - 1.0f) + 1.0f) * 0.5f * gm1;
+        const float iz = (((qz - bmz) * bsz - 1.0f) + 1.0f) * 0.5f * gm1;
+        const float fx0 = floorf(ix), fy0 = floorf(iy), fz0 = floorf(iz);
+        const float wx1 = ix - fx0, wy1 = iy - fy0, wz1 = iz - fz0;
+        const float wx0 = (fx0 + 1.0f) - ix, wy0 = (fy0 + 1.0f) - iy, wz0 = (fz0 + 1.0f) - iz;
+        const int x0 = (int)fminf(fmaxf(fx0, -2.0f), gm1 + 1.0f);
+        const int y0 = (int)fminf(fmaxf(fy0, -2.0f), gm1 + 1.0f);
+        const int z0 = (int)fminf(fmaxf(fz0, -2.0f), gm1 + 1.0f);
+        float w = 0.f, dwx = 0.f, dwy = 0.f, dwz = 0.f;   // value and d/d(ix,iy,iz)
+        const float dLdw_base = gA0 * qx + gA1 * qy + gA2 * qz + gws;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const int ox = c & 1, oy = (c >> 1) & 1, oz = c >> 2;
+            const int xi = x0 + ox, yi = y0 + oy, zi = z0 + oz;
+            if (xi >= 0 && xi < G && yi >= 0 && yi < G && zi >= 0 && zi < G) {
+                const float wx = ox ? wx1 : wx0, wy = oy ? wy1 : wy0, wz = oz ? wz1 : wz0;
+                const int idx = zi * GG + yi * G + xi;
+                const float v = vb[idx];
+                w += v * wx * wy * wz;
+                dwx += v * (ox ? 1.f : -1.f) * wy * wz;
+                dwy += v * wx * (oy ? 1.f : -1.f) * wz;
+                dwz += v * wx * wy * (oz ? 1.f : -1.f);
+                const float contrib = dLdw_base * wx * wy * wz;
+                if (contrib != 0.f) atomicAdd(dvb + idx, contrib);
+            }
+        }
+        // d pos = w gA + dL/dw * grad_pos(w);  d ix / d qx = bsx * 0.5 * (G-1)
+        const float dqx = w * gA0 + dLdw_base * dwx * (bsx * 0.5f * gm1);
+        const float dqy = w * gA1 + dLdw_base * dwy * (bsy * 0.5f * gm1);
+        const float dqz = w * gA2 + dLdw_base * dwz * (bsz * 0.5f * gm1);
+        acc[0] += dqx * px; acc[1] += dqx * py; acc[2] += dqx * pz;
+        acc[3] += dqy * px; acc[4] += dqy * py; acc[5] += dqy * pz;
+        acc[6] += dqz * px; acc[7] += dqz * py; acc[8] += dqz * pz;
+        acc[9] += dqx; acc[10] += dqy; acc[11] += dqz;
+    }
+    // block reduction: wave butterflies, then 4 partials through LDS
+    __shared__ float red[4][12];
+#pragma unroll
+    for (int i = 0; i < 12; ++i) {
+        float v = acc[i];
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][i] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < 12) {
+        const float v = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+        if (threadIdx.x < 9) atomicAdd(d_Rs + b * 9 + threadIdx.x, v);
+        else atomicAdd(d_Ts + b * 3 + (threadIdx.x - 9), v);
+    }
+}
+
+}  // namespace hnrf
+
+using namespace hnrf;
+
+extern "C" int hnrf_composite_bwd(const float* raw, const float* fg_mask, const float* z_vals, const float* rays_d,
+                                  const float* bgcolor, const float* g_rgb, const float* g_alpha,
+                                  const float* g_depth, int64_t R, int S, float* d_raw, float* d_mask,
+                                  void* stream) {
+    HNRF_REQUIRE(raw && fg_mask && z_vals && rays_d && bgcolor && g_rgb && d_raw && d_mask, HNRF_E_ARG,
+                 "hnrf_composite_bwd: null pointer");
+    HNRF_REQUIRE(R >= 0 && S >= 2, HNRF_E_ARG, "hnrf_composite_bwd: bad dims");
+    HNRF_REQUIRE(S <= 512, HNRF_E_UNSUPPORTED, "hnrf_composite_bwd: S=%d > 512 not built", S);
+    HNRF_REQUIRE((((uintptr_t)raw | (uintptr_t)d_raw) & 15) == 0, HNRF_E_ARG, "hnrf_composite_bwd: raw/d_raw alignment");
+    if (R == 0) return HNRF_OK;
+    const int64_t blocks = (R + 3) / 4;
+    hipStream_t st = (hipStream_t)stream;
+    const int spl = (S + 63) / 64;
+#define HNRF_LAUNCH_CB(N)                                                                                          \
+    hipLaunchKernelGGL(composite_bwd_kernel<N>, dim3((unsigned)blocks), dim3(256), 0, st, (const float4*)raw,     \
+                       fg_mask, z_vals, rays_d, bgcolor, g_rgb, g_alpha, g_depth, R, S, (float4*)d_raw, d_mask)
+    if (spl <= 1) HNRF_LAUNCH_CB(1);
+    else if (spl <= 2) HNRF_LAUNCH_CB(2);
+    else if (spl <= 4) HNRF_LAUNCH_CB(4);
+    else HNRF_LAUNCH_CB(8);
+#undef HNRF_LAUNCH_CB
+    return check_launch("hnrf_composite_bwd");
+}
+
+extern "C" int hnrf_pe_bwd(const float* x, const float* g, const float* hann_w, int64_t P, int n_bands,
+                           int include_input, int accumulate, float* dx, void* stream) {
+    HNRF_REQUIRE(x && g && dx, HNRF_E_ARG, "hnrf_pe_bwd: null pointer");
+    HNRF_REQUIRE(P >= 0 && n_bands >= 1 && n_bands <= 16, HNRF_E_ARG, "hnrf_pe_bwd: bad dims");
+    if (P == 0) return HNRF_OK;
+    const int64_t n = P * 3;
+    hipLaunchKernelGGL(pe_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, g,
+                       hann_w, P, n_bands, include_input, accumulate, dx);
+    return check_launch("hnrf_pe_bwd");
+}
+
+extern "C" int hnrf_sample_warp_bwd(const float* rays_o, const float* rays_d, const float* z_vals,
+                                    const float* motion_Rs, const float* motion_Ts, const float* vol,
+                                    const float* bbox_min, const float* bbox_scale, const float* x_skel,
+                                    const float* fg_mask, const float* g_x_skel, const float* g_mask, int64_t R,
+                                    int S, int B, int G, float* d_vol, float* d_Rs, float* d_Ts, void* stream) {
+    HNRF_REQUIRE(rays_o && rays_d && z_vals && motion_Rs && motion_Ts && vol && bbox_min && bbox_scale && x_skel &&
+                     fg_mask && g_x_skel && g_mask && d_vol && d_Rs && d_Ts,
+                 HNRF_E_ARG, "hnrf_sample_warp_bwd: null pointer");
+    HNRF_REQUIRE(R >= 0 && S >= 2 && B >= 1 && B <= 65535 && G >= 2 && G <= 1024, HNRF_E_ARG,
+                 "hnrf_sample_warp_bwd: bad dims");
+    hipStream_t st = (hipStream_t)stream;
+    // d_vol covers the B bone channels only; the caller owns the (zero) background-channel gradient
+    if (hipMemsetAsync(d_vol, 0, (size_t)B * G * G * G * sizeof(float), st) != hipSuccess ||
+        hipMemsetAsync(d_Rs, 0, (size_t)B * 9 * sizeof(float), st) != hipSuccess ||
+        hipMemsetAsync(d_Ts, 0, (size_t)B * 3 * sizeof(float), st) != hipSuccess) {
+        set_error("hnrf_sample_warp_bwd: memset failed");
+        return HNRF_E_LAUNCH;
+    }
+    if (R == 0) return HNRF_OK;
+    const int64_t P = R * (int64_t)S;
+    int64_t blocks = (P + 255) / 256;
+    if (blocks > 1024) blocks = 1024;     // grid-stride: few, long blocks keep the 12-value reduction cheap
+    hipLaunchKernelGGL(sample_warp_bwd_kernel, dim3((unsigned)blocks, (unsigned)B), dim3(256), 0, st, rays_o, rays_d,
+                       z_vals, motion_Rs, motion_Ts, vol, bbox_min, bbox_scale, x_skel, fg_mask, g_x_skel, g_mask, P,
+                       S, G, d_vol, d_Rs, d_Ts);
+    return check_launch("hnrf_sample_warp_bwd");
+}

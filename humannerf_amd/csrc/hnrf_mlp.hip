@@ -139,10 +139,13 @@ constexpr int64_t NR_FLOATS = NR_B_OFF + 6 * 128 + 32;
 // One layer for this wave's 32 samples.  K order = [a (NGA groups) | b (NGB groups)]
 // when A_FIRST else [b | a].  `wptr` is this lane's cursor into the packed image
 // (float4 units, already offset by lane); `ring` holds the next PF groups.
+// `save` (training): this lane's row of the layer's [P, 32 NT] activation matrix, or nullptr;
+// lane half h writes features 32 t + 8 q + 4 h + (0..3) as one float4 per (t, q).
 template <int NT, int NGA, int NGB, bool A_FIRST, bool RELU, int NA, int NB, int NO>
 __device__ __forceinline__ void mlp_layer(const float4* __restrict__& wptr, float4 (&ring)[PF],
                                           const float* __restrict__ bias, const float (&a)[NA],
-                                          const float (&b)[NB], float (&out)[NO]) {
+                                          const float (&b)[NB], float (&out)[NO], float* save = nullptr,
+                                          int h = 0) {
     static_assert(NA >= NGA * 4 && NB >= NGB * 4 && NO >= NT * 16, "operand arrays too small");
     static_assert((NT * (NGA + NGB)) % PF == 0, "layer must keep the prefetch ring phase");
     constexpr int NG = NGA + NGB;
@@ -177,6 +180,13 @@ __device__ __forceinline__ void mlp_layer(const float4* __restrict__& wptr, floa
             const float v = acc[r] + bs[r];
             out[t * 16 + r] = RELU ? fmaxf(v, 0.f) : v;
         }
+        if (save != nullptr) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                *reinterpret_cast<float4*>(save + 32 * t + 8 * q + 4 * h) =
+                    make_float4(out[t * 16 + 4 * q], out[t * 16 + 4 * q + 1], out[t * 16 + 4 * q + 2],
+                                out[t * 16 + 4 * q + 3]);
+        }
     }
 }
 
@@ -186,9 +196,13 @@ __device__ __forceinline__ void ring_fill(const float4* __restrict__ wptr, float
 }
 
 // K3.  grid = ceil(P / 128) workgroups of 4 independent waves x 32 samples.
+// SAVE (training forward): also writes the positional encoding pe_out [P,63] (reference column
+// order) and the 8 post-ReLU activation matrices acts [8][P][256] that the backward GEMMs read.
+template <bool SAVE>
 __global__ __launch_bounds__(256) void canonical_f32_kernel(const float* __restrict__ xyz,
                                                             const float* __restrict__ packed, int64_t P,
-                                                            float4* __restrict__ raw) {
+                                                            float4* __restrict__ raw, float* __restrict__ pe_out,
+                                                            float* __restrict__ acts) {
     const int lane = threadIdx.x & 63;
     const int h = lane >> 5;
     const int64_t sample = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 32 + (lane & 31);
@@ -208,6 +222,16 @@ __global__ __launch_bounds__(256) void canonical_f32_kernel(const float* __restr
     }
     pe[30] = h ? x[1] : x[0];
     pe[31] = h ? 0.f : x[2];
+    float* save = nullptr;                       // this lane's activation row (advances one layer per step)
+    if (SAVE && sample < P) {
+        save = acts + sample * 256;
+#pragma unroll
+        for (int j = 0; j < 32; ++j) {
+            const int col = pe_col(PE_CANONICAL, j, h);
+            if (col >= 0) pe_out[sample * 63 + col] = pe[j];
+        }
+    }
+    const int64_t act_stride = P * 256;
 
     const float4* wptr = reinterpret_cast<const float4*>(packed) + lane;
     const float* bias = packed + CNL_B_OFF + h * 16;
@@ -216,23 +240,27 @@ __global__ __launch_bounds__(256) void canonical_f32_kernel(const float* __restr
 
     float hA[128], hB[128];
     const float none[1] = {0.f};
-    mlp_layer<8, 8, 0, true, true>(wptr, ring, bias, pe, none, hA);
+    mlp_layer<8, 8, 0, true, true>(wptr, ring, bias, pe, none, hA, save, h);
     bias += 256;
+    if (save) save += act_stride;
 #pragma unroll 1
     for (int l = 1; l <= 4; ++l) {
-        mlp_layer<8, 0, 32, true, true>(wptr, ring, bias, none, hA, hB);
+        mlp_layer<8, 0, 32, true, true>(wptr, ring, bias, none, hA, hB, save, h);
         bias += 256;
+        if (save) save += act_stride;
 #pragma unroll
         for (int i = 0; i < 128; ++i) hA[i] = hB[i];
     }
-    mlp_layer<8, 8, 32, true, true>(wptr, ring, bias, pe, hA, hB);   // skip: [PE | h]
+    mlp_layer<8, 8, 32, true, true>(wptr, ring, bias, pe, hA, hB, save, h);   // skip: [PE | h]
     bias += 256;
+    if (save) save += act_stride;
 #pragma unroll
     for (int i = 0; i < 128; ++i) hA[i] = hB[i];
 #pragma unroll 1
     for (int l = 6; l <= 7; ++l) {
-        mlp_layer<8, 0, 32, true, true>(wptr, ring, bias, none, hA, hB);
+        mlp_layer<8, 0, 32, true, true>(wptr, ring, bias, none, hA, hB, save, h);
         bias += 256;
+        if (save) save += act_stride;
 #pragma unroll
         for (int i = 0; i < 128; ++i) hA[i] = hB[i];
     }
@@ -242,11 +270,13 @@ __global__ __launch_bounds__(256) void canonical_f32_kernel(const float* __restr
     if (h == 0 && sample < P) raw[sample] = make_float4(o[0], o[1], o[2], o[3]);
 }
 
-// K2.  Same structure, width 128.
+// K2.  Same structure, width 128.  SAVE: pe_out [P,36], acts [6][P][128].
+template <bool SAVE>
 __global__ __launch_bounds__(256) void nonrigid_f32_kernel(const float* __restrict__ x_skel,
                                                            const float* __restrict__ hann_w,
                                                            const float* __restrict__ packed, int64_t P,
-                                                           float* __restrict__ xyz, float* __restrict__ offsets) {
+                                                           float* __restrict__ xyz, float* __restrict__ offsets,
+                                                           float* __restrict__ pe_out, float* __restrict__ acts) {
     const int lane = threadIdx.x & 63;
     const int h = lane >> 5;
     const int64_t sample = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 32 + (lane & 31);
@@ -265,6 +295,13 @@ __global__ __launch_bounds__(256) void nonrigid_f32_kernel(const float* __restri
     }
     pe[18] = 0.f;
     pe[19] = 0.f;
+    float* save = nullptr;
+    if (SAVE && sample < P) {
+        save = acts + sample * 128;
+#pragma unroll
+        for (int j = 0; j < 18; ++j) pe_out[sample * 36 + pe_col(PE_NONRIGID, j, h)] = pe[j];
+    }
+    const int64_t act_stride = P * 128;
 
     const float4* wptr = reinterpret_cast<const float4*>(packed) + lane;
     const float* bias = packed + NR_B_OFF + h * 16;
@@ -273,18 +310,21 @@ __global__ __launch_bounds__(256) void nonrigid_f32_kernel(const float* __restri
 
     float hA[64], hB[64];
     const float none[1] = {0.f};
-    mlp_layer<4, 5, 0, true, true>(wptr, ring, bias, pe, none, hA);
+    mlp_layer<4, 5, 0, true, true>(wptr, ring, bias, pe, none, hA, save, h);
     bias += 128;
+    if (save) save += act_stride;
 #pragma unroll 1
     for (int l = 1; l <= 3; ++l) {
-        mlp_layer<4, 0, 16, true, true>(wptr, ring, bias, none, hA, hB);
+        mlp_layer<4, 0, 16, true, true>(wptr, ring, bias, none, hA, hB, save, h);
         bias += 128;
+        if (save) save += act_stride;
 #pragma unroll
         for (int i = 0; i < 64; ++i) hA[i] = hB[i];
     }
-    mlp_layer<4, 5, 16, false, true>(wptr, ring, bias, pe, hA, hB);   // skip: [h | PE]
+    mlp_layer<4, 5, 16, false, true>(wptr, ring, bias, pe, hA, hB, save, h);   // skip: [h | PE]
     bias += 128;
-    mlp_layer<4, 0, 16, true, true>(wptr, ring, bias, none, hB, hA);
+    if (save) save += act_stride;
+    mlp_layer<4, 0, 16, true, true>(wptr, ring, bias, none, hB, hA, save, h);
     bias += 128;
     float o[16];
     mlp_layer<1, 0, 16, true, false>(wptr, ring, bias, none, hA, o);
@@ -400,9 +440,23 @@ extern "C" int hnrf_canonical_fwd(const float* xyz, const void* packed, int mode
                  "hnrf_canonical_fwd: packed/raw must be 16-byte aligned");
     if (P == 0) return HNRF_OK;
     if (mode == HNRF_MLP_F16X3) return canonical16_fwd(xyz, packed, P, raw, (hipStream_t)stream);
-    hipLaunchKernelGGL(canonical_f32_kernel, dim3((unsigned)((P + 127) / 128)), dim3(256), 0, (hipStream_t)stream,
-                       xyz, (const float*)packed, P, (float4*)raw);
+    hipLaunchKernelGGL(canonical_f32_kernel<false>, dim3((unsigned)((P + 127) / 128)), dim3(256), 0,
+                       (hipStream_t)stream, xyz, (const float*)packed, P, (float4*)raw, nullptr, nullptr);
     return check_launch("hnrf_canonical_fwd");
+}
+
+extern "C" int hnrf_canonical_fwd_train(const float* xyz, const void* packed, int mode, int64_t P, float* raw,
+                                        float* pe_out, float* acts, void* stream) {
+    HNRF_REQUIRE(xyz && packed && raw && pe_out && acts, HNRF_E_ARG, "hnrf_canonical_fwd_train: null pointer");
+    HNRF_REQUIRE(mode == HNRF_MLP_F32, HNRF_E_UNSUPPORTED,
+                 "hnrf_canonical_fwd_train: only HNRF_MLP_F32 saves activations (mode %d)", mode);
+    HNRF_REQUIRE(P >= 0 && (P + 127) / 128 < 2147483647LL, HNRF_E_ARG, "hnrf_canonical_fwd_train: bad P");
+    HNRF_REQUIRE((((uintptr_t)packed | (uintptr_t)raw | (uintptr_t)acts) & 15) == 0, HNRF_E_ARG,
+                 "hnrf_canonical_fwd_train: packed/raw/acts must be 16-byte aligned");
+    if (P == 0) return HNRF_OK;
+    hipLaunchKernelGGL(canonical_f32_kernel<true>, dim3((unsigned)((P + 127) / 128)), dim3(256), 0,
+                       (hipStream_t)stream, xyz, (const float*)packed, P, (float4*)raw, pe_out, acts);
+    return check_launch("hnrf_canonical_fwd_train");
 }
 
 extern "C" int hnrf_nonrigid_fwd(const float* x_skel, const float* hann_w, const void* packed, int mode, int64_t P,
@@ -414,7 +468,23 @@ extern "C" int hnrf_nonrigid_fwd(const float* x_skel, const float* hann_w, const
     HNRF_REQUIRE(((uintptr_t)packed & 15) == 0, HNRF_E_ARG, "hnrf_nonrigid_fwd: packed must be 16-byte aligned");
     if (P == 0) return HNRF_OK;
     if (mode == HNRF_MLP_F16X3) return nonrigid16_fwd(x_skel, hann_w, packed, P, xyz, offsets, (hipStream_t)stream);
-    hipLaunchKernelGGL(nonrigid_f32_kernel, dim3((unsigned)((P + 127) / 128)), dim3(256), 0, (hipStream_t)stream,
-                       x_skel, hann_w, (const float*)packed, P, xyz, offsets);
+    hipLaunchKernelGGL(nonrigid_f32_kernel<false>, dim3((unsigned)((P + 127) / 128)), dim3(256), 0,
+                       (hipStream_t)stream, x_skel, hann_w, (const float*)packed, P, xyz, offsets, nullptr, nullptr);
     return check_launch("hnrf_nonrigid_fwd");
+}
+
+extern "C" int hnrf_nonrigid_fwd_train(const float* x_skel, const float* hann_w, const void* packed, int mode,
+                                       int64_t P, float* xyz, float* offsets, float* pe_out, float* acts,
+                                       void* stream) {
+    HNRF_REQUIRE(x_skel && hann_w && packed && xyz && pe_out && acts, HNRF_E_ARG,
+                 "hnrf_nonrigid_fwd_train: null pointer");
+    HNRF_REQUIRE(mode == HNRF_MLP_F32, HNRF_E_UNSUPPORTED,
+                 "hnrf_nonrigid_fwd_train: only HNRF_MLP_F32 saves activations (mode %d)", mode);
+    HNRF_REQUIRE(P >= 0 && (P + 127) / 128 < 2147483647LL, HNRF_E_ARG, "hnrf_nonrigid_fwd_train: bad P");
+    HNRF_REQUIRE((((uintptr_t)packed | (uintptr_t)acts) & 15) == 0, HNRF_E_ARG,
+                 "hnrf_nonrigid_fwd_train: packed/acts must be 16-byte aligned");
+    if (P == 0) return HNRF_OK;
+    hipLaunchKernelGGL(nonrigid_f32_kernel<true>, dim3((unsigned)((P + 127) / 128)), dim3(256), 0,
+                       (hipStream_t)stream, x_skel, hann_w, (const float*)packed, P, xyz, offsets, pe_out, acts);
+    return check_launch("hnrf_nonrigid_fwd_train");
 }

@@ -26,6 +26,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import ops
+from .autograd import RenderRays
 from .config import cfg, amd_option
 
 SMPL_PARENT = [-1, 0, 0, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 9, 9, 12, 13, 14, 16,
@@ -304,10 +305,7 @@ class Network(nn.Module):
         """network.py:647-789.  Extra keyword ``t_rand`` (N,S) injects the
         stratified-sampling uniforms (parity tests); unknown kwargs are ignored
         like the reference's **kwargs."""
-        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
-            raise NotImplementedError(
-                'training through the HIP path needs the backward kernels (not built in this round); '
-                'call under torch.no_grad() for rendering')
+        train_path = torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
         iter_val = float(iter_val)
         dev = dst_Rs.device
         f32 = lambda t: t.to(dtype=torch.float32)
@@ -329,12 +327,14 @@ class Network(nn.Module):
         self.motion_weights_vol = vol
 
         mode = self._mlp_mode()
-        cnl_packed = self._canonical_packed()
-        nr_packed, hann_w = None, None
+        nr_packed, cnl_packed, hann_w = None, None, None
         if not ignore_nr:
-            nr_packed = self._nonrigid_packed(cond)
             hann_w = hann_window_weights(iter_val, nr_cfg.multires, nr_cfg.kick_in_iter,
                                          nr_cfg.full_band_iter).to(dev)
+        if not train_path:
+            cnl_packed = self._canonical_packed()
+            if not ignore_nr:
+                nr_packed = self._nonrigid_packed(cond)
 
         rays_o, rays_d = rays[0], rays[1]
         rays_shape = rays_d.shape
@@ -358,6 +358,11 @@ class Network(nn.Module):
         chunks = []
         for i in range(0, N, int(cfg.chunk)):                              # network.py:333
             sl = slice(i, min(i + int(cfg.chunk), N))
+            if train_path:
+                chunks.append(self._render_rays_train(rays_o[sl], rays_d[sl], near[sl], far[sl],
+                                                      None if t_rand is None else t_rand[sl], motion_Rs, motion_Ts,
+                                                      vol, bbox_min, bbox_scale, hann_w, cond, bg, S, not ignore_nr))
+                continue
             chunks.append(self._render_rays(rays_o[sl], rays_d[sl], near[sl], far[sl],
                                             None if t_rand is None else t_rand[sl],
                                             motion_Rs, motion_Ts, vol, bbox_min, bbox_scale, hann_w,
@@ -365,6 +370,20 @@ class Network(nn.Module):
         out = {k: (torch.cat([c[k] for c in chunks], 0) if len(chunks) > 1 else chunks[0][k]) for k in chunks[0]}
         lead = list(rays_shape[:-1])
         return {k: v.reshape(lead + list(v.shape[1:])) for k, v in out.items()}
+
+    def _render_rays_train(self, rays_o, rays_d, near, far, t_rand, motion_Rs, motion_Ts, vol, bbox_min, bbox_scale,
+                           hann_w, cond, bg, S, use_nonrigid):
+        """Differentiable chunk: autograd.RenderRays (fp32 MFMA kernels + saved activations).  Only the
+        three outputs the trainer's loss reads are produced (trainer.py:121)."""
+        nr = self.non_rigid_mlp.module.linears()
+        cn = self.cnl_mlp.module.linears()
+        if hann_w is None:
+            hann_w = torch.ones(6, device=rays_o.device)
+        params = [l.weight for l in nr] + [l.bias for l in nr] + [l.weight for l in cn] + [l.bias for l in cn]
+        rgb, alpha, depth = RenderRays.apply(rays_o, rays_d, near, far, t_rand, bbox_min, bbox_scale, hann_w,
+                                             cond.detach().contiguous(), bg, S, use_nonrigid, motion_Rs, motion_Ts,
+                                             vol, *params)
+        return {'rgb': rgb, 'alpha': alpha, 'depth': depth}
 
     def _render_rays(self, rays_o, rays_d, near, far, t_rand, motion_Rs, motion_Ts, vol, bbox_min, bbox_scale,
                      hann_w, nr_packed, cnl_packed, bg, S, mode, diag):

@@ -184,3 +184,73 @@ def render_rays(rays_o, rays_d, near, far, t_rand, motion_Rs, motion_Ts, vol, bb
                                         ev[0], ev[1], _stream()),
                'hnrf_render_rays_fwd')
     return out
+
+
+# ----------------------------------------------------------------------------- training
+def canonical_train(xyz, packed):
+    """hnrf_canonical_fwd_train: raw (...,4), pe (P,63), acts (8,P,256).  fp32 mode only."""
+    lib = _lib.load()
+    _chk(xyz, packed)
+    P = xyz.numel() // 3
+    dev = xyz.device
+    raw = torch.empty(*xyz.shape[:-1], 4, device=dev)
+    pe = torch.empty(P, 63, device=dev)
+    acts = torch.empty(8, P, 256, device=dev)
+    _lib.check(lib.hnrf_canonical_fwd_train(_ptr(xyz), _ptr(packed), MLP_MODES['f32'], P, _ptr(raw), _ptr(pe),
+                                            _ptr(acts), _stream()), 'hnrf_canonical_fwd_train')
+    return raw, pe, acts
+
+
+def nonrigid_train(x_skel, hann_w, packed):
+    """hnrf_nonrigid_fwd_train: xyz, offsets, pe (P,36), acts (6,P,128)."""
+    lib = _lib.load()
+    _chk(x_skel, hann_w, packed)
+    P = x_skel.numel() // 3
+    dev = x_skel.device
+    xyz, offsets = torch.empty_like(x_skel), torch.empty_like(x_skel)
+    pe = torch.empty(P, 36, device=dev)
+    acts = torch.empty(6, P, 128, device=dev)
+    _lib.check(lib.hnrf_nonrigid_fwd_train(_ptr(x_skel), _ptr(hann_w), _ptr(packed), MLP_MODES['f32'], P, _ptr(xyz),
+                                           _ptr(offsets), _ptr(pe), _ptr(acts), _stream()), 'hnrf_nonrigid_fwd_train')
+    return xyz, offsets, pe, acts
+
+
+def composite_bwd(raw, fg_mask, z_vals, rays_d, bgcolor, g_rgb, g_alpha=None, g_depth=None):
+    lib = _lib.load()
+    _chk(raw, fg_mask, z_vals, rays_d, bgcolor, g_rgb, g_alpha, g_depth)
+    R, S = z_vals.shape
+    d_raw, d_mask = torch.empty_like(raw), torch.empty_like(fg_mask)
+    _lib.check(lib.hnrf_composite_bwd(_ptr(raw), _ptr(fg_mask), _ptr(z_vals), _ptr(rays_d), _ptr(bgcolor), _ptr(g_rgb),
+                                      _ptr(g_alpha), _ptr(g_depth), R, S, _ptr(d_raw), _ptr(d_mask), _stream()),
+               'hnrf_composite_bwd')
+    return d_raw, d_mask
+
+
+def pe_bwd(x, g, hann_w, n_bands, include_input, out=None):
+    """d PE -> d position; accumulates into ``out`` when given."""
+    lib = _lib.load()
+    _chk(x, g, hann_w, out)
+    P = x.numel() // 3
+    assert g.shape[-1] == (3 if include_input else 0) + 6 * n_bands and g.numel() // g.shape[-1] == P
+    acc = out is not None
+    if out is None:
+        out = torch.empty_like(x)
+    _lib.check(lib.hnrf_pe_bwd(_ptr(x), _ptr(g), _ptr(hann_w), P, n_bands, int(include_input), int(acc), _ptr(out),
+                               _stream()), 'hnrf_pe_bwd')
+    return out
+
+
+def sample_warp_bwd(rays_o, rays_d, z_vals, motion_Rs, motion_Ts, vol, bbox_min, bbox_scale, x_skel, fg_mask,
+                    g_x_skel, g_mask):
+    """Returns d_vol (same shape as vol; background channel zero), d_Rs (B,3,3), d_Ts (B,3)."""
+    lib = _lib.load()
+    _chk(rays_o, rays_d, z_vals, motion_Rs, motion_Ts, vol, bbox_min, bbox_scale, x_skel, fg_mask, g_x_skel, g_mask)
+    R, S = z_vals.shape
+    B, G = motion_Rs.shape[0], vol.shape[-1]
+    d_vol = torch.zeros_like(vol)
+    d_Rs, d_Ts = torch.empty_like(motion_Rs), torch.empty_like(motion_Ts)
+    _lib.check(lib.hnrf_sample_warp_bwd(_ptr(rays_o), _ptr(rays_d), _ptr(z_vals), _ptr(motion_Rs), _ptr(motion_Ts),
+                                        _ptr(vol), _ptr(bbox_min), _ptr(bbox_scale), _ptr(x_skel), _ptr(fg_mask),
+                                        _ptr(g_x_skel), _ptr(g_mask), R, S, B, G, _ptr(d_vol), _ptr(d_Rs), _ptr(d_Ts),
+                                        _stream()), 'hnrf_sample_warp_bwd')
+    return d_vol, d_Rs, d_Ts

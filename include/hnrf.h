@@ -127,6 +127,47 @@ int hnrf_render_rays_fwd(const float* rays_o, const float* rays_d,
                          float* rgb, float* alpha, float* depth,
                          void* ev_mlp_start, void* ev_mlp_stop, void* stream);
 
+/* =============================== training (backward) ===============================
+ * The reference trains through torch.autograd over the ops above (trainer.py:206-220).
+ * Here: the forward runs the *_fwd_train variants (HNRF_MLP_F32 only) which also save the
+ * positional encodings and the post-ReLU activation matrices; the MLP weight/input
+ * gradients are plain library GEMMs on those matrices (dW = dZ^T X, dX = dZ W, done by the
+ * host with rocBLAS through torch.mm); the stages around the MLPs have the kernels below. */
+
+/* pe_out [P,63] (columns in fourier.py order), acts [8][P][256] post-ReLU outputs of
+ * pts_linears.{0..14}. */
+int hnrf_canonical_fwd_train(const float* xyz, const void* packed, int mode, int64_t P,
+                             float* raw, float* pe_out, float* acts, void* stream);
+/* pe_out [P,36] (hannw_fourier.py order, window weights applied), acts [6][P][128]. */
+int hnrf_nonrigid_fwd_train(const float* x_skel, const float* hann_w, const void* packed,
+                            int mode, int64_t P, float* xyz, float* offsets,
+                            float* pe_out, float* acts, void* stream);
+
+/* Backward of hnrf_composite_fwd w.r.t. raw and fg_mask (autograd of network.py:355-379).
+ *  g_rgb [R,3]; g_alpha, g_depth [R] or NULL.  Outputs d_raw [R,S,4], d_mask [R,S]. */
+int hnrf_composite_bwd(const float* raw, const float* fg_mask, const float* z_vals,
+                       const float* rays_d, const float* bgcolor,
+                       const float* g_rgb, const float* g_alpha, const float* g_depth,
+                       int64_t R, int S, float* d_raw, float* d_mask, void* stream);
+
+/* Backward of the positional encodings w.r.t. the position (fourier.py / hannw_fourier.py).
+ *  g [P, 3*include_input + 6*n_bands]; hann_w [n_bands] or NULL; dx [P,3] written or
+ *  accumulated into. */
+int hnrf_pe_bwd(const float* x, const float* g, const float* hann_w, int64_t P, int n_bands,
+                int include_input, int accumulate, float* dx, void* stream);
+
+/* Backward of hnrf_sample_warp_fwd w.r.t. the weight volume and the motion bases
+ * (autograd of network.py:392-444, including grid_sample's gradient w.r.t. the grid).
+ *  z_vals, x_skel, fg_mask: outputs of the forward; g_x_skel [R,S,3], g_mask [R,S].
+ *  Outputs (overwritten): d_vol [B,G,G,G], d_Rs [B,3,3], d_Ts [B,3]. */
+int hnrf_sample_warp_bwd(const float* rays_o, const float* rays_d, const float* z_vals,
+                         const float* motion_Rs, const float* motion_Ts, const float* vol,
+                         const float* bbox_min, const float* bbox_scale,
+                         const float* x_skel, const float* fg_mask,
+                         const float* g_x_skel, const float* g_mask,
+                         int64_t R, int S, int B, int G,
+                         float* d_vol, float* d_Rs, float* d_Ts, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

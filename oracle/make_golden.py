@@ -164,6 +164,32 @@ def main():
     t_rand = np.random.RandomState(7).rand(R, 128).astype(np.float32)
     metas['perturb_s128'] = run_case('perturb_s128', fr, 1e7, 128, perturb=1.0, t_rand=t_rand)
 
+    # ---- gradients of a scalar loss through the reference (training path, trainer.py:206-220)
+    cfg.N_samples, cfg.perturb, cfg.ignore_non_rigid_motions = 64, 0.0, False
+    net.train()
+    for p_ in net.parameters():
+        p_.grad = None
+    frg = scene.synthetic_frame(H=512, W=512, focal_at_512=1250.0, ray_stride=73)
+    Rg = frg['rays'].shape[1]
+    lw = np.random.RandomState(11).randn(Rg, 5).astype(np.float32)
+    out = net(**frame_tensors(frg), iter_val=30000.0)
+    loss = (out['rgb'] * torch.from_numpy(lw[:, :3])).sum() + (out['alpha'] * torch.from_numpy(lw[:, 3])).sum() \
+        + 0.1 * (out['depth'] * torch.from_numpy(lw[:, 4])).sum()
+    loss.backward()
+    gsave = {'loss_weights': lw, 'loss': np.float32(loss.item())}
+    for k, p_ in net.named_parameters():
+        g = p_.grad
+        gsave['norm/' + k] = np.float32(0.0 if g is None else g.norm().item())
+        if g is not None and g.numel() <= 70000:
+            gsave['grad/' + k] = g.numpy().copy()
+        elif g is not None:
+            gsave['head/' + k] = g.reshape(-1)[:4096].numpy().copy()
+    np.savez_compressed(os.path.join(GOLD, 'grad_s64.npz'), **gsave)
+    metas['grad_s64'] = dict(iter_val=30000.0, N_samples=64, ray_stride=73, focal_at_512=1250.0, n_rays=int(Rg),
+                             loss=float(loss.item()))
+    print('grad golden: rays', Rg, 'loss', loss.item(), 'tensors', sum(1 for k in gsave if k.startswith('norm/')))
+    net.eval()
+
     # ---- reference CPU throughput (indicative)
     cfg.N_samples, cfg.perturb, cfg.ignore_non_rigid_motions = 128, 0.0, False
     frb = scene.synthetic_frame(H=512, W=512, focal_at_512=1700.0, ray_stride=4)   # 128x128 rays of C2

@@ -1,0 +1,151 @@
+"""Training path on the GPU: gradients from the HIP forward/backward (autograd.RenderRays)
+vs the reference's gradients for the same scalar loss (tests/golden/grad_s64.npz), plus
+kernel-level checks of the backward kernels against torch.autograd through the oracle."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from tests.test_grad_oracle import compare_grads, grad_frame, reference_loss
+
+pytestmark = pytest.mark.gpu
+
+
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device('cuda:0')
+
+
+def test_network_gradients_match_reference(seeded_params, golden_dir):
+    from humannerf_amd.config import cfg
+    from humannerf_amd.network import Network
+    with open(os.path.join(golden_dir, 'meta.json')) as f:
+        meta = json.load(f)['grad_s64']
+    g = np.load(os.path.join(golden_dir, 'grad_s64.npz'))
+    fr = grad_frame(meta)
+    net = Network()
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in seeded_params.items()})
+    net = net.to(dev()).train()
+    keys = ['rays', 'near', 'far', 'dst_Rs', 'dst_Ts', 'cnl_gtfms', 'motion_weights_priors', 'dst_posevec',
+            'cnl_bbox_min_xyz', 'cnl_bbox_scale_xyz', 'bgcolor']
+    data = {k: torch.from_numpy(np.ascontiguousarray(fr[k])).to(dev()) for k in keys}
+    cfg.N_samples, cfg.perturb, cfg.ignore_non_rigid_motions = meta['N_samples'], 0.0, False
+    try:
+        out = net(**data, iter_val=meta['iter_val'])
+        assert set(out) == {'rgb', 'alpha', 'depth'}
+        loss = reference_loss(out, torch.from_numpy(g['loss_weights']).to(dev()))
+        loss.backward()
+    finally:
+        cfg.N_samples, cfg.perturb = 128, 1.0
+    assert abs(float(loss) - meta['loss']) <= 2e-4 * max(1.0, abs(meta['loss']))
+    grads = {k: (p.grad.cpu().numpy() if p.grad is not None else np.zeros(tuple(p.shape), np.float32))
+             for k, p in net.named_parameters()}
+    compare_grads(grads, g, rel_norm=5e-3, cos_min=0.999)
+
+
+def test_composite_bwd_kernel():
+    from humannerf_amd import ops
+    from oracle import oracle
+    rs = np.random.RandomState(5)
+    R, S = 19, 128
+    raw = rs.randn(R, S, 4).astype(np.float32) * 2
+    raw[..., 3] = rs.randn(R, S) * 20 + 5
+    mask = rs.uniform(0, 1.1, (R, S)).astype(np.float32)
+    z = np.sort(1 + rs.uniform(0, 3, (R, S)).astype(np.float32), axis=1)
+    rays_d = rs.randn(R, 3).astype(np.float32)
+    bg = np.array([200., 100., 30.], dtype=np.float32)
+    g_rgb, g_a, g_d = rs.randn(R, 3).astype(np.float32), rs.randn(R).astype(np.float32), rs.randn(R).astype(np.float32)
+    T = lambda a: torch.from_numpy(a).to(dev())
+    d_raw, d_mask = ops.composite_bwd(T(raw), T(mask), T(z), T(rays_d), T(bg), T(g_rgb), T(g_a), T(g_d))
+    rt = torch.from_numpy(raw).double().requires_grad_(True)
+    mt = torch.from_numpy(mask).double().requires_grad_(True)
+    o = oracle.raw2outputs(rt, mt, torch.from_numpy(z).double(), torch.from_numpy(rays_d).double(),
+                           torch.zeros(R, S, 3).double(), torch.from_numpy(bg).double())
+    loss = (o['rgb'] * torch.from_numpy(g_rgb)).sum() + (o['alpha'] * torch.from_numpy(g_a)).sum() \
+        + (o['depth'] * torch.from_numpy(g_d)).sum()
+    loss.backward()
+    for got, ref in ((d_raw, rt.grad), (d_mask, mt.grad)):
+        err = (got.cpu().double() - ref).abs().max() / max(1.0, float(ref.abs().max()))
+        assert err <= 2e-5, float(err)
+
+
+def test_sample_warp_bwd_kernel():
+    from humannerf_amd import ops
+    from oracle import oracle
+    rs = np.random.RandomState(9)
+    R, S, B, G = 23, 64, 24, 16
+    rays_o = rs.uniform(-0.3, 0.3, (R, 3)).astype(np.float32)
+    rays_d = rs.uniform(-1, 1, (R, 3)).astype(np.float32)
+    near = rs.uniform(0.0, 0.2, (R, 1)).astype(np.float32)
+    far = near + rs.uniform(0.5, 1.0, (R, 1)).astype(np.float32)
+    Rs = (np.eye(3)[None] + 0.1 * rs.randn(B, 3, 3)).astype(np.float32)
+    Ts = (0.1 * rs.randn(B, 3)).astype(np.float32)
+    vol = rs.uniform(0, 0.1, (B + 1, G, G, G)).astype(np.float32)
+    bmin = np.array([-1.0, -1.1, -0.9], dtype=np.float32)
+    bscale = (2.0 / np.array([2.0, 2.2, 1.8])).astype(np.float32)
+    T = lambda a: torch.from_numpy(a).to(dev())
+    z, xs, mask, _ = ops.sample_warp(T(rays_o), T(rays_d), T(near), T(far), None, T(Rs), T(Ts), T(vol), T(bmin),
+                                     T(bscale), S)
+    gx = rs.randn(R, S, 3).astype(np.float32)
+    gm = rs.randn(R, S).astype(np.float32)
+    d_vol, d_Rs, d_Ts = ops.sample_warp_bwd(T(rays_o), T(rays_d), z, T(Rs), T(Ts), T(vol), T(bmin), T(bscale), xs,
+                                            mask, T(gx), T(gm))
+    # oracle autograd in fp64
+    Rt = torch.from_numpy(Rs).double().requires_grad_(True)
+    Tt = torch.from_numpy(Ts).double().requires_grad_(True)
+    vt = torch.from_numpy(vol).double().requires_grad_(True)
+    zo = oracle.z_values(torch.from_numpy(near).double(), torch.from_numpy(far).double(), S)
+    pts = torch.from_numpy(rays_o).double()[:, None] + torch.from_numpy(rays_d).double()[:, None] * zo[:, :, None]
+    xo, mo, _ = oracle.sample_motion_fields(pts.reshape(-1, 3), Rt, Tt, vt, torch.from_numpy(bmin).double(),
+                                            torch.from_numpy(bscale).double())
+    loss = (xo * torch.from_numpy(gx).double().reshape(-1, 3)).sum() + (mo * torch.from_numpy(gm).double().reshape(-1)).sum()
+    loss.backward()
+    for name, got, ref in (('vol', d_vol, vt.grad), ('Rs', d_Rs, Rt.grad), ('Ts', d_Ts, Tt.grad)):
+        err = (got.cpu().double() - ref).abs().max() / max(1e-6, float(ref.abs().max()))
+        assert err <= 2e-3, (name, float(err))
+    assert float(d_vol[-1].abs().max()) == 0       # background channel never sampled
+
+
+def test_pe_bwd_kernel():
+    from humannerf_amd import ops
+    from oracle import oracle
+    rs = np.random.RandomState(2)
+    P = 777
+    x = rs.uniform(-1.2, 1.2, (P, 3)).astype(np.float32)
+    T = lambda a: torch.from_numpy(a).to(dev())
+    for nb, inc, hw in ((10, True, None), (6, False, np.array([1, 1, 0.7, 0.2, 0, 0], dtype=np.float32))):
+        C = (3 if inc else 0) + 6 * nb
+        g = rs.randn(P, C).astype(np.float32)
+        got = ops.pe_bwd(T(x), T(g), None if hw is None else T(hw), nb, inc)
+        xt = torch.from_numpy(x).double().requires_grad_(True)
+        pe = oracle.fourier_pe(xt, nb) if inc else oracle.hann_pe(xt, torch.from_numpy(hw).double())
+        (pe * torch.from_numpy(g).double()).sum().backward()
+        err = (got.cpu().double() - xt.grad).abs().max() / float(xt.grad.abs().max())
+        assert err <= 1e-4, float(err)
+
+
+def test_training_forward_equals_inference_forward():
+    """The activation-saving forward returns the same raw values as the inference kernel, and the
+    saved activations are what the oracle computes."""
+    from humannerf_amd import ops
+    from oracle import oracle
+    from tests.test_gpu_parity import _mlp_states
+    rs = np.random.RandomState(4)
+    st = _mlp_states(rs)
+    P = 333
+    xyz = rs.uniform(-1.2, 1.2, (P, 3)).astype(np.float32)
+    idx = [0, 2, 4, 6, 8, 10, 12, 14]
+    T = lambda a: torch.from_numpy(a).to(dev())
+    ws = [T(st[f'cnl_mlp.module.pts_linears.{i}.weight']) for i in idx] + [T(st['cnl_mlp.module.output_linear.0.weight'])]
+    bs = [T(st[f'cnl_mlp.module.pts_linears.{i}.bias']) for i in idx] + [T(st['cnl_mlp.module.output_linear.0.bias'])]
+    packed = ops.canonical_pack(ws, bs, 'f32')
+    raw = ops.canonical(T(xyz), packed, 'f32')
+    raw_t, pe, acts = ops.canonical_train(T(xyz), packed)
+    assert torch.equal(raw, raw_t)
+    pe_ref = oracle.fourier_pe(torch.from_numpy(xyz), 10)
+    assert (pe.cpu() - pe_ref).abs().max() <= 1e-6
+    h = torch.relu(torch.nn.functional.linear(pe_ref, torch.from_numpy(st['cnl_mlp.module.pts_linears.0.weight']),
+                                              torch.from_numpy(st['cnl_mlp.module.pts_linears.0.bias'])))
+    assert (acts[0].cpu() - h).abs().max() <= 1e-5
