@@ -46,7 +46,7 @@ def main():
     ap.add_argument('--mode', default=os.environ.get('HNRF_MLP_MODE', 'f16x3'), choices=['f32', 'f16x3'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-rays', type=int, default=4096)
-    ap.add_argument('--train-steps', type=int, default=5, help='extra: timed training iterations (0 = skip)')
+    ap.add_argument('--train-steps', type=int, default=10, help='extra: timed training iterations (0 = skip)')
     args = ap.parse_args()
 
     rank = int(os.environ.get('RANK', 0))
@@ -182,7 +182,8 @@ def main():
         tb['near'], tb['far'] = data['near'][idx].contiguous(), data['far'][idx].contiguous()
         tb['target_rgbs'] = torch.from_numpy(np.random.RandomState(3 + rank).rand(idx.numel(), 3).astype(np.float32)).to(dev)
         trainer = Trainer(net, world_size=world)
-        trainer.train_step(tb)                   # warm-up (allocations, rocBLAS handles)
+        for _ in range(3):
+            trainer.train_step(tb)               # warm-up (allocator growth, rocBLAS solution selection)
         torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()

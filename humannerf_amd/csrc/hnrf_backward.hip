@@ -140,6 +140,7 @@ __global__ void pe_bwd_kernel(const float* __restrict__ x, const float* __restri
 //   dL/dpos_b = w_b gA + dL/dw_b * grad_pos trilinear(vol_b)        (grid_sample's grid gradient)
 //   dL/dvol_b[corner] += dL/dw_b * corner weight                     (global float atomics)
 //   dL/dR_b += dL/dpos_b (x) x,   dL/dT_b += dL/dpos_b               (block reduction, 12 atomics)
+template <bool LDS_VOL>
 __global__ __launch_bounds__(256) void sample_warp_bwd_kernel(
     const float* __restrict__ rays_o, const float* __restrict__ rays_d, const float* __restrict__ z_vals,
     const float* __restrict__ Rs, const float* __restrict__ Ts, const float* __restrict__ vol,
@@ -158,6 +159,14 @@ __global__ __launch_bounds__(256) void sample_warp_bwd_kernel(
     const int GG = G * G;
     const float* vb = vol + (size_t)b * G * GG;
     float* dvb = d_vol + (size_t)b * G * GG;
+    // LDS_VOL: this block accumulates its bone's whole G^3 gradient grid in LDS (128 KiB at G = 32;
+    // samples of one ray chunk hammer the same few voxels, global float atomics on one line run
+    // ~14x below their spread rate) and flushes the touched voxels once at the end.
+    extern __shared__ float lvol[];
+    if (LDS_VOL) {
+        for (int i = threadIdx.x; i < G * GG; i += 256) lvol[i] = 0.f;
+        __syncthreads();
+    }
 
     float acc[12];
 #pragma unroll
@@ -203,7 +212,10 @@ __global__ __launch_bounds__(256) void sample_warp_bwd_kernel(
                 dwy += v * wx * (oy ? 1.f : -1.f) * wz;
                 dwz += v * wx * wy * (oz ? 1.f : -1.f);
                 const float contrib = dLdw_base * wx * wy * wz;
-                if (contrib != 0.f) atomicAdd(dvb + idx, contrib);
+                if (contrib != 0.f) {
+                    if (LDS_VOL) atomicAdd(lvol + idx, contrib);
+                    else atomicAdd(dvb + idx, contrib);
+                }
             }
         }
         // d pos = w gA + dL/dw * grad_pos(w);  d ix / d qx = bsx * 0.5 * (G-1)
@@ -214,6 +226,13 @@ __global__ __launch_bounds__(256) void sample_warp_bwd_kernel(
         acc[3] += dqy * px; acc[4] += dqy * py; acc[5] += dqy * pz;
         acc[6] += dqz * px; acc[7] += dqz * py; acc[8] += dqz * pz;
         acc[9] += dqx; acc[10] += dqy; acc[11] += dqz;
+    }
+    if (LDS_VOL) {
+        __syncthreads();
+        for (int i = threadIdx.x; i < G * GG; i += 256) {
+            const float v = lvol[i];
+            if (v != 0.f) atomicAdd(dvb + i, v);
+        }
     }
     // block reduction: wave butterflies, then 4 partials through LDS
     __shared__ float red[4][12];
@@ -292,9 +311,29 @@ extern "C" int hnrf_sample_warp_bwd(const float* rays_o, const float* rays_d, co
     if (R == 0) return HNRF_OK;
     const int64_t P = R * (int64_t)S;
     int64_t blocks = (P + 255) / 256;
-    if (blocks > 1024) blocks = 1024;     // grid-stride: few, long blocks keep the 12-value reduction cheap
-    hipLaunchKernelGGL(sample_warp_bwd_kernel, dim3((unsigned)blocks, (unsigned)B), dim3(256), 0, st, rays_o, rays_d,
-                       z_vals, motion_Rs, motion_Ts, vol, bbox_min, bbox_scale, x_skel, fg_mask, g_x_skel, g_mask, P,
-                       S, G, d_vol, d_Rs, d_Ts);
+    const size_t lds = (size_t)G * G * G * sizeof(float);
+    if (lds + 256 <= 160 * 1024 && P >= 65536) {
+        // one 128-KiB LDS grid per block -> 1 block per CU; ~2 waves of blocks over the chip
+        static bool attr_set = false;
+        if (!attr_set) {
+            if (hipFuncSetAttribute((const void*)sample_warp_bwd_kernel<true>,
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) != hipSuccess) {
+                set_error("hnrf_sample_warp_bwd: cannot reserve LDS");
+                return HNRF_E_LAUNCH;
+            }
+            attr_set = true;
+        }
+        int64_t bx = 512 / B;                        // blocks per bone
+        if (bx < 1) bx = 1;
+        if (bx > blocks) bx = blocks;
+        hipLaunchKernelGGL(sample_warp_bwd_kernel<true>, dim3((unsigned)bx, (unsigned)B), dim3(256), lds, st, rays_o,
+                           rays_d, z_vals, motion_Rs, motion_Ts, vol, bbox_min, bbox_scale, x_skel, fg_mask, g_x_skel,
+                           g_mask, P, S, G, d_vol, d_Rs, d_Ts);
+    } else {
+        if (blocks > 1024) blocks = 1024;     // grid-stride: few, long blocks keep the 12-value reduction cheap
+        hipLaunchKernelGGL(sample_warp_bwd_kernel<false>, dim3((unsigned)blocks, (unsigned)B), dim3(256), 0, st,
+                           rays_o, rays_d, z_vals, motion_Rs, motion_Ts, vol, bbox_min, bbox_scale, x_skel, fg_mask,
+                           g_x_skel, g_mask, P, S, G, d_vol, d_Rs, d_Ts);
+    }
     return check_launch("hnrf_sample_warp_bwd");
 }

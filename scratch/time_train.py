@@ -1,0 +1,35 @@
+"""Scratch: wall-time split of one training iteration."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from humannerf_amd import scene
+from humannerf_amd.config import cfg
+from humannerf_amd.network import Network
+from humannerf_amd.train import Trainer, image_loss, update_lr
+from oracle.seeded import default_shapes, seeded_state
+dev = torch.device('cuda:0')
+state = seeded_state(default_shapes(), 0)
+net = Network(); net.load_state_dict({k: torch.from_numpy(v) for k, v in state.items()}); net = net.to(dev).train()
+fr = scene.synthetic_frame(H=512, W=512, focal_at_512=1700.0)
+keys = ['rays', 'near', 'far', 'dst_Rs', 'dst_Ts', 'cnl_gtfms', 'motion_weights_priors', 'dst_posevec', 'cnl_bbox_min_xyz', 'cnl_bbox_scale_xyz', 'bgcolor']
+data = {k: torch.from_numpy(np.ascontiguousarray(fr[k])).to(dev) for k in keys}
+import numpy as _np
+_idx = []
+for k in range(6):
+    y0, x0 = 96 + 48 * k, 80 + 56 * k
+    yy, xx = _np.meshgrid(_np.arange(y0, y0 + 32), _np.arange(x0, x0 + 32), indexing='ij')
+    _idx.append((yy * 512 + xx).reshape(-1))
+idx = torch.from_numpy(_np.concatenate(_idx)).to(dev) if len(sys.argv) > 1 else torch.arange(0, 6144, device=dev) * 37 % (512 * 512)
+tb = dict(data); tb['rays'] = data['rays'][:, idx].contiguous(); tb['near'] = data['near'][idx].contiguous(); tb['far'] = data['far'][idx].contiguous()
+tgt = torch.rand(6144, 3, device=dev)
+cfg.perturb, cfg.N_samples = 1.0, 128
+tr = Trainer(net)
+def sync(): torch.cuda.synchronize(); return time.perf_counter()
+for it in range(4):
+    t0 = sync(); tr.optimizer.zero_grad(set_to_none=True)
+    out = net(**tb, iter_val=float(it + 1)); t1 = sync()
+    loss, _ = image_loss(out['rgb'][None, None], tgt[None, None]); t2 = sync()
+    loss.backward(); t3 = sync()
+    tr.optimizer.step(); t4 = sync()
+    update_lr(tr.optimizer, it + 1); t5 = sync()
+    print('iter %d: fwd %.1f loss %.1f bwd %.1f opt %.1f lr %.1f ms' % (it, (t1-t0)*1e3, (t2-t1)*1e3, (t3-t2)*1e3, (t4-t3)*1e3, (t5-t4)*1e3))

@@ -71,11 +71,12 @@ def test_composite_bwd_kernel():
         assert err <= 2e-5, float(err)
 
 
-def test_sample_warp_bwd_kernel():
+@pytest.mark.parametrize('R,G', [(23, 16), (1100, 32)])      # small: global atomics; large: LDS-privatised grid
+def test_sample_warp_bwd_kernel(R, G):
     from humannerf_amd import ops
     from oracle import oracle
     rs = np.random.RandomState(9)
-    R, S, B, G = 23, 64, 24, 16
+    S, B = 64, 24
     rays_o = rs.uniform(-0.3, 0.3, (R, 3)).astype(np.float32)
     rays_d = rs.uniform(-1, 1, (R, 3)).astype(np.float32)
     near = rs.uniform(0.0, 0.2, (R, 1)).astype(np.float32)
@@ -102,9 +103,14 @@ def test_sample_warp_bwd_kernel():
                                             torch.from_numpy(bscale).double())
     loss = (xo * torch.from_numpy(gx).double().reshape(-1, 3)).sum() + (mo * torch.from_numpy(gm).double().reshape(-1)).sum()
     loss.backward()
+    # d w / d pos of a trilinear lookup jumps at voxel faces: a sample whose fp32 position falls on the
+    # other side of a face than its fp64 position flips one term of the 1.7 M-term motion-base sums
+    # (~1e-4 of the samples sit within fp32 rounding of a face), so those reductions agree to ~1 %
+    # only; the volume gradient (no spatial derivative) agrees to 2e-3
+    tol = {'vol': 2e-3, 'Rs': 2e-3 if R < 100 else 3e-2, 'Ts': 2e-3 if R < 100 else 3e-2}
     for name, got, ref in (('vol', d_vol, vt.grad), ('Rs', d_Rs, Rt.grad), ('Ts', d_Ts, Tt.grad)):
         err = (got.cpu().double() - ref).abs().max() / max(1e-6, float(ref.abs().max()))
-        assert err <= 2e-3, (name, float(err))
+        assert err <= tol[name], (name, float(err))
     assert float(d_vol[-1].abs().max()) == 0       # background channel never sampled
 
 
