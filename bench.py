@@ -119,8 +119,12 @@ def main():
     traffic = None
     pmc = os.path.join(ROOT, 'profiles', 'r01_pmc_canonical.json')
     if os.path.isfile(pmc):
+        # measured offline (two separate --pmc passes, FETCH_SIZE doubled per the gfx950 correction);
+        # committed under profiles/ because PMC counters cannot be read from inside this process
         with open(pmc) as f:
-            traffic = json.load(f).get('hbm_bytes_per_launch')
+            rec = json.load(f)
+        if rec.get('kernel') == 'canonical_%s_kernel' % args.mode and rec.get('samples_per_launch') == int(samples_per_launch):
+            traffic = rec.get('hbm_bytes_per_launch')
     roofline = {'bound': 'mfma', 'kernel': 'canonical_%s_kernel' % args.mode, 'achieved': round(achieved, 2),
                 'peak': PEAK_TFLOPS[args.mode], 'unit': 'TFLOP/s', 'frac': round(achieved / PEAK_TFLOPS[args.mode], 4),
                 'traffic': traffic, 'launches': launches, 'avg_launch_ms': round(avg_s * 1e3, 4),

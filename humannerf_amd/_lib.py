@@ -8,7 +8,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libhnrf.so')
+LIB_PATH = os.environ.get('HNRF_LIB_PATH', os.path.join(_HERE, 'libhnrf.so'))   # override: diagnostic builds only
 
 _vp, _i64, _int, _sz = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_size_t
 

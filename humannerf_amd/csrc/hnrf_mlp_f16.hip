@@ -217,6 +217,9 @@ struct Pipe {
     unsigned ph;         // ring slot of the slab being consumed
     unsigned bias_off;   // byte offset of the current tile's bias record
     int wave;
+#ifdef HNRF_STAMP
+    unsigned long long t_last, sum_k, sum_b;   // diagnostic build only: cycles in k-loops / between them
+#endif
 };
 
 // Epilogue of one PAIR of accumulator registers (2i, 2i+1) of a finished tile: combine the
@@ -224,15 +227,18 @@ struct Pipe {
 // next layer's B-operand fragment (k-step 2t + (i>>2), elements 2(i&3), 2(i&3)+1).
 template <bool RELU>
 __device__ __forceinline__ void epi_pair(const f32x16& a1, const f32x16& a2, int i, h16x8& hi, h16x8& lo) {
-    f32x2 x = {a1[2 * i] + a2[2 * i] * LO_INV, a1[2 * i + 1] + a2[2 * i + 1] * LO_INV};
+    // scalar f32 ops on purpose: beside MFMAs the packed forms (v_pk_add/mul_f32) cost more issue time
+    float x0 = fmaf(a2[2 * i], LO_INV, a1[2 * i]);
+    float x1 = fmaf(a2[2 * i + 1], LO_INV, a1[2 * i + 1]);
     if (RELU) {
-        x[0] = __builtin_amdgcn_fmed3f(x[0], 0.f, 65504.f);
-        x[1] = __builtin_amdgcn_fmed3f(x[1], 0.f, 65504.f);
+        x0 = __builtin_amdgcn_fmed3f(x0, 0.f, 65504.f);
+        x1 = __builtin_amdgcn_fmed3f(x1, 0.f, 65504.f);
     }
-    const h16x2 hh = __builtin_convertvector(x, h16x2);
-    const f32x2 back = __builtin_convertvector(hh, f32x2);
-    const f32x2 rem = (x - back) * LO_SCALE;
-    const h16x2 ll = __builtin_convertvector(rem, h16x2);
+    const h16x2 hh = __builtin_convertvector(f32x2{x0, x1}, h16x2);
+    // (x - hi) * 2^11 == fma(x, 2^11, -(hi * 2^11)): both products exact
+    const float r0 = fmaf(x0, LO_SCALE, -((float)hh[0] * LO_SCALE));
+    const float r1 = fmaf(x1, LO_SCALE, -((float)hh[1] * LO_SCALE));
+    const h16x2 ll = __builtin_convertvector(f32x2{r0, r1}, h16x2);
     const int e = 2 * (i & 3);
     hi[e] = hh[0];
     hi[e + 1] = hh[1];
@@ -266,7 +272,12 @@ __device__ __forceinline__ void layer16(Pipe& p, int nb1, int nb2, const h16x8 (
         // slab n+2 -> ring slot (ph + 2) % RING (last read during step n-1: fenced by the previous barrier)
         const int nissue = (s + 2 < NS) ? NBLK * TPS : (s + 2 == NS ? nb1 : nb2);
         const unsigned slot2 = p.ph == 0 ? 2 : p.ph - 1;
-        slab_issue(p.gi, p.lds_base + p.ring_off + slot2 * p.slab_bytes, nissue, p.wave);
+        // its 1-KiB pieces are issued one per k-step INSIDE this slab's MFMA stream (an LDS-DMA issue
+        // costs ~100-150 cycles of the wave's issue slot: 8-10 of them in front of the tile idle the
+        // matrix pipe for ~1000 cycles per tile -- measured with cycle stamps)
+        const char* dsrc = p.gi + p.wave * 1024;
+        const unsigned ddst = p.lds_base + p.ring_off + slot2 * p.slab_bytes + p.wave * 1024;
+        const int dcnt = nissue / 4;
         p.gi += nissue * 1024;
 #pragma unroll
         for (int tt = 0; tt < TPS; ++tt) {
@@ -292,6 +303,9 @@ __device__ __forceinline__ void layer16(Pipe& p, int nb1, int nb2, const h16x8 (
                     qxl[i] = lds_ld8(pe + (2 * i + 1) * 1024);
                 }
             }
+#ifdef HNRF_STAMP
+            { const unsigned long long t0 = __builtin_readcyclecounter(); p.sum_b += t0 - p.t_last; p.t_last = t0; }
+#endif
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int ks = 0; ks < NK; ++ks) {
@@ -317,6 +331,17 @@ __device__ __forceinline__ void layer16(Pipe& p, int nb1, int nb2, const h16x8 (
                 acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, xh, acc1, 0, 0, 0);
                 acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, xl, acc2, 0, 0, 0);
                 acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, xh, acc2, 0, 0, 0);
+                {   // DMA piece (gk - 1) of slab n+2 at slab-local k-step gk = tt NK + ks
+                    constexpr int MAXP = (TPS * NK - 1) < 10 ? (TPS * NK - 1) : 10;
+                    const int i = tt * NK + ks - 1;
+                    if (i >= 0 && i < MAXP) {
+                        if (s + 2 < NS) {                      // piece count known at compile time
+                            if (i < NBLK * TPS / 4) dma_piece(dsrc + i * 4096, lane * 16, ddst + i * 4096);
+                        } else if (i < dcnt) {                 // wave-uniform branch (layer-boundary slabs)
+                            dma_piece(dsrc + i * 4096, lane * 16, ddst + i * 4096);
+                        }
+                    }
+                }
                 if (t > 0) {      // pending epilogue of tile t-1: pair i runs at k-step (i * NK) / 8
 #pragma unroll
                     for (int i = 0; i < 8; ++i)
@@ -327,8 +352,21 @@ __device__ __forceinline__ void layer16(Pipe& p, int nb1, int nb2, const h16x8 (
                             asm volatile("" : "+v"(oh[2 * (t - 1) + (i >> 2)]), "+v"(ol[2 * (t - 1) + (i >> 2)]));
                         }
                 }
+                // issue order inside the k-step: keep the matrix pipe fed -- one MFMA, then <= 6 of the
+                // pending VALU / LDS fillers (PMC: 6.4 non-MFMA instructions per MFMA; clumped behind the
+                // third MFMA they left the pipe idle for a third of every k-step)
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);
                 __builtin_amdgcn_sched_barrier(0);
             }
+#ifdef HNRF_STAMP
+            { const unsigned long long t1 = __builtin_readcyclecounter(); p.sum_k += t1 - p.t_last; p.t_last = t1; }
+#endif
             pacc1 = acc1;
             pacc2 = acc2;
         }
@@ -358,6 +396,10 @@ __device__ __forceinline__ Pipe pipe_start(const char* packed, int64_t bias_img_
     p.slab_bytes = slab_bytes;
     p.ph = 0;
     p.bias_off = 0;
+#ifdef HNRF_STAMP
+    p.t_last = __builtin_readcyclecounter();
+    p.sum_k = p.sum_b = 0;
+#endif
     slab_issue(packed + bias_img_off, p.lds_base, bias_bytes / 1024, p.wave);
     slab_issue(packed, p.lds_base + p.ring_off, nb0, p.wave);
     slab_issue(packed + nb0 * 1024, p.lds_base + p.ring_off + slab_bytes, nb1, p.wave);
@@ -428,6 +470,13 @@ __global__ __launch_bounds__(256) void canonical_f16x3_kernel(const float* __res
     layer16<1, 1, 0, 16, false>(p, 0, 0, hA_h, hA_l, dh, dl, last);
     const float* ob = reinterpret_cast<const float*>(packed + CNL16_BIAS + CNL16_BIAS_LDS);   // head bias: scalar loads
     if (h == 0 && sample < P) raw[sample] = make_float4(last[0] + ob[0], last[1] + ob[1], last[2] + ob[2], last[3] + ob[3]);
+#ifdef HNRF_STAMP
+    if (threadIdx.x == 0 && blockIdx.x < 4096) {   // stamps leave through a buffer nothing else reads
+        const unsigned long long te = __builtin_readcyclecounter();
+        unsigned long long* dbg = (unsigned long long*)(const_cast<char*>(packed) + CNL16_BYTES);
+        dbg[blockIdx.x * 4 + 0] = p.sum_k; dbg[blockIdx.x * 4 + 1] = p.sum_b + (te - p.t_last);
+    }
+#endif
 }
 
 // K2, f16x3 (width 128: 4 tiles, 8 k-steps).

@@ -26,7 +26,7 @@ DEFAULTS = dict(
     N_samples=128, perturb=0.0, chunk=32768, netchunk=300000, total_bones=24,
     nr_multires=6, nr_kick_in_iter=10000, nr_full_band_iter=50000,
     cnl_multires=10, pose_decoder_kick_in_iter=0, pose_decoder_off=False,
-    ignore_non_rigid_motions=False,
+    ignore_non_rigid_motions=False, use_grid_sample=False,
 )
 
 
@@ -67,7 +67,7 @@ def pose_refine(state, dst_posevec, dst_Rs):
 def motion_basis(dst_Rs, dst_Ts, cnl_gtfms):
     """MotionBasisComputer.forward, core/utils/network_util.py:125-156."""
     B = dst_Rs.shape[0]
-    G = torch.zeros(B, 4, 4, dtype=dst_Rs.dtype)
+    G = torch.zeros(B, 4, 4, dtype=dst_Rs.dtype, device=dst_Rs.device)
     G[:, :3, :3] = dst_Rs
     G[:, :3, 3] = dst_Ts
     G[:, 3, 3] = 1.0
@@ -98,15 +98,15 @@ def weight_volume(state, priors):
 
 
 # --------------------------------------------------------------------- a6
-def linspace01(S, dtype):
+def linspace01(S, dtype, device=None):
     """torch.linspace(0., 1., steps=S) as used at network.py:457."""
-    return torch.linspace(0., 1., steps=S, dtype=dtype)
+    return torch.linspace(0., 1., steps=S, dtype=dtype, device=device)
 
 
 def z_values(near, far, S, t_rand=None):
     """_get_samples_along_ray + _stratified_sampling, network.py:455-471.
     near/far: (R,1).  ``t_rand`` (R,S) in [0,1) replaces torch.rand."""
-    t = linspace01(S, near.dtype)
+    t = linspace01(S, near.dtype, near.device)
     z = near * (1. - t) + far * t
     if t_rand is not None:
         mids = .5 * (z[..., 1:] + z[..., :-1])
@@ -142,16 +142,22 @@ def trilinear_zeros(vol, g):
     return out
 
 
-def sample_motion_fields(pts, Rs, Ts, vol, bbox_min, bbox_scale):
+def sample_motion_fields(pts, Rs, Ts, vol, bbox_min, bbox_scale, use_grid_sample=False):
     """_sample_motion_fields, network.py:392-444.  pts (P,3); vol (B+1,D,H,W)
     with the background channel last (dropped, 404).  Returns x_skel (P,3),
-    fg mask = sum w (P,), unnormalised weights (P,B)."""
+    fg mask = sum w (P,), unnormalised weights (P,B).  ``use_grid_sample``: call
+    F.grid_sample like the reference does (the eager-GPU timing comparator) instead
+    of the written-out trilinear (the independent checker)."""
     nb = vol.shape[0] - 1
     ws, poss = [], []
     for i in range(nb):
         pos = torch.matmul(Rs[i], pts.T).T + Ts[i]
         g = (pos - bbox_min[None]) * bbox_scale[None] - 1.0
-        ws.append(trilinear_zeros(vol[i], g))
+        if use_grid_sample:
+            ws.append(F.grid_sample(vol[None, i:i + 1], g[None, None, None], padding_mode='zeros',
+                                    align_corners=True)[0, 0, 0, 0])
+        else:
+            ws.append(trilinear_zeros(vol[i], g))
         poss.append(pos)
     w = torch.stack(ws, dim=-1)                        # (P,B)
     wsum = torch.sum(w, dim=-1, keepdim=True)
@@ -252,7 +258,7 @@ def per_frame_setup(state, data, iter_val, opt):
     posevec = data['dst_posevec'].to(dt)
     if iter_val >= opt['pose_decoder_kick_in_iter'] and not opt['pose_decoder_off']:
         dst_Rs = pose_refine(state, posevec, dst_Rs)
-    hw = hann_weights(iter_val, opt['nr_multires'], opt['nr_kick_in_iter'], opt['nr_full_band_iter'], dt)
+    hw = hann_weights(iter_val, opt['nr_multires'], opt['nr_kick_in_iter'], opt['nr_full_band_iter'], dt).to(dst_Rs.device)
     cond = posevec[None]
     if iter_val < opt['nr_kick_in_iter']:
         cond = torch.zeros_like(cond) * cond           # network.py:735-737
@@ -267,7 +273,8 @@ def render_rays(state, fr, rays_o, rays_d, near, far, bbox_min, bbox_scale, bgco
     R = rays_o.shape[0]
     z = z_values(near, far, S, t_rand)
     pts = rays_o[:, None, :] + rays_d[:, None, :] * z[:, :, None]
-    x_skel, mask, bmw = sample_motion_fields(pts.reshape(-1, 3), fr['Rs'], fr['Ts'], fr['vol'], bbox_min, bbox_scale)
+    x_skel, mask, bmw = sample_motion_fields(pts.reshape(-1, 3), fr['Rs'], fr['Ts'], fr['vol'], bbox_min, bbox_scale,
+                                             opt['use_grid_sample'])
     raws, xyzs, offs = [], [], []
     for s in range(0, x_skel.shape[0], opt['netchunk']):        # network.py:252
         xs = x_skel[s:s + opt['netchunk']]
@@ -288,10 +295,12 @@ def render_rays(state, fr, rays_o, rays_d, near, far, bbox_min, bbox_scale, bgco
     return out
 
 
-def render(state, data, iter_val=1e7, t_rand=None, dtype=torch.float32, **overrides):
+def render(state, data, iter_val=1e7, t_rand=None, dtype=torch.float32, device=None, **overrides):
     """Network.forward, network.py:647-789.  ``data`` holds the per-frame
     tensors of row a1 (numpy arrays or tensors).  Returns the 11 reference
-    keys (+ underscore-prefixed intermediates)."""
+    keys (+ underscore-prefixed intermediates).  ``device``: where the eager
+    torch ops run (default CPU; a GPU device gives the "reference op sequence in
+    PyTorch-ROCm eager" comparator of SURVEY.md section 8d)."""
     opt = dict(DEFAULTS)
     opt.update(overrides)
     d = {k: (torch.as_tensor(v).to(dtype) if torch.as_tensor(v).is_floating_point() else torch.as_tensor(v))
@@ -299,6 +308,11 @@ def render(state, data, iter_val=1e7, t_rand=None, dtype=torch.float32, **overri
                                           'motion_weights_priors', 'dst_posevec', 'cnl_bbox_min_xyz',
                                           'cnl_bbox_scale_xyz', 'bgcolor')}
     state = {k: torch.as_tensor(v).to(dtype) for k, v in state.items()}
+    if device is not None:
+        d = {k: v.to(device) for k, v in d.items()}
+        state = {k: v.to(device) for k, v in state.items()}
+        if t_rand is not None:
+            t_rand = torch.as_tensor(t_rand).to(device)
     fr = per_frame_setup(state, d, iter_val, opt)
     rays_o, rays_d = d['rays'][0].reshape(-1, 3), d['rays'][1].reshape(-1, 3)
     outs = []
