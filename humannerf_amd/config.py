@@ -124,6 +124,11 @@ _DEFAULTS = {
         # cache the motion-weight volume across eval-mode frames while the
         # decoder parameters and the priors tensor are unchanged.
         'cache_weight_volume': True,
+        # lean rendering only: skip the MLPs for samples whose foreground likelihood (sum of
+        # skinning weights) is below this; bounds |d rgb|, |d alpha| by ~2 * N_samples * cull_eps.
+        # 0 = evaluate every sample exactly like the reference.  1e-9 already drops ~55 % of the
+        # samples of a typical frame at an error 100x below the reference's own fp32 noise.
+        'cull_eps': 0.0,
     },
 }
 

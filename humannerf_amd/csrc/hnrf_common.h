@@ -33,8 +33,9 @@ size_t canonical16_bytes();
 size_t nonrigid16_bytes();
 int canonical16_pack(const float* const* w, const float* const* b, void* packed, hipStream_t st);
 int nonrigid16_pack(const float* const* w, const float* const* b, const float* cond, void* packed, hipStream_t st);
-int canonical16_fwd(const float* xyz, const void* packed, int64_t P, float* raw, hipStream_t st);
+int canonical16_fwd(const float* xyz, const void* packed, int64_t P, float* raw, const int* idx, const int* count,
+                    hipStream_t st);
 int nonrigid16_fwd(const float* x_skel, const float* hann_w, const void* packed, int64_t P, float* xyz,
-                   float* offsets, hipStream_t st);
+                   float* offsets, const int* idx, const int* count, hipStream_t st);
 
 }  // namespace hnrf

@@ -19,7 +19,7 @@ template <int SPL>
 __global__ __launch_bounds__(256) void composite_kernel(
     const float4* __restrict__ raw, const float* __restrict__ fg_mask, const float* __restrict__ z_vals,
     const float* __restrict__ rays_d, const float* __restrict__ xyz, const float* __restrict__ bgcolor,
-    int64_t R, int S,
+    int64_t R, int S, float cull_eps,
     float* __restrict__ rgb_out, float* __restrict__ alpha_out, float* __restrict__ depth_out,
     float* __restrict__ weights_out, float* __restrict__ rgb_on_rays,
     float* __restrict__ cnl_xyz, float* __restrict__ cnl_rgb, float* __restrict__ cnl_weight) {
@@ -53,10 +53,12 @@ __global__ __launch_bounds__(256) void composite_kernel(
         float dist = (s >= S - 1) ? 1e10f : (zn - zv[i]);
         dist *= dnorm;
         const float sig = fmaxf(rw[i].w, 0.f);
-        al[i] = (1.0f - expf(-sig * dist)) * mk[i];
-        cr[i] = 1.0f / (1.0f + expf(-rw[i].x));
-        cg[i] = 1.0f / (1.0f + expf(-rw[i].y));
-        cb[i] = 1.0f / (1.0f + expf(-rw[i].z));
+        // culled samples (fg_mask < cull_eps) were never evaluated: their raw is undefined -> weight 0
+        const bool live = !(mk[i] < cull_eps);
+        al[i] = live ? (1.0f - expf(-sig * dist)) * mk[i] : 0.f;
+        cr[i] = live ? 1.0f / (1.0f + expf(-rw[i].x)) : 0.f;
+        cg[i] = live ? 1.0f / (1.0f + expf(-rw[i].y)) : 0.f;
+        cb[i] = live ? 1.0f / (1.0f + expf(-rw[i].z)) : 0.f;
         if (s < S) tl *= (1.0f - al[i] + 1e-10f);
     }
     // inclusive product scan over lanes, then shift to exclusive
@@ -139,7 +141,7 @@ __global__ __launch_bounds__(256) void composite_kernel(
 
 extern "C" int hnrf_composite_fwd(const float* raw, const float* fg_mask, const float* z_vals,
                                   const float* rays_d, const float* xyz, const float* bgcolor,
-                                  int64_t R, int S,
+                                  int64_t R, int S, float cull_eps,
                                   float* rgb, float* alpha, float* depth,
                                   float* weights, float* rgb_on_rays,
                                   float* cnl_xyz, float* cnl_rgb, float* cnl_weight,
@@ -158,7 +160,7 @@ extern "C" int hnrf_composite_fwd(const float* raw, const float* fg_mask, const 
     const int spl = (S + 63) / 64;
 #define HNRF_LAUNCH_COMPOSITE(N)                                                                                  \
     hipLaunchKernelGGL(composite_kernel<N>, dim3((unsigned)blocks), dim3(256), 0, st, (const float4*)raw, fg_mask, \
-                       z_vals, rays_d, xyz, bgcolor, R, S, rgb, alpha, depth, weights, rgb_on_rays, cnl_xyz,      \
+                       z_vals, rays_d, xyz, bgcolor, R, S, cull_eps, rgb, alpha, depth, weights, rgb_on_rays, cnl_xyz,      \
                        cnl_rgb, cnl_weight)
     if (spl <= 1) HNRF_LAUNCH_COMPOSITE(1);
     else if (spl <= 2) HNRF_LAUNCH_COMPOSITE(2);

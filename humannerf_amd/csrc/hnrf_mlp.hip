@@ -202,11 +202,18 @@ template <bool SAVE>
 __global__ __launch_bounds__(256) void canonical_f32_kernel(const float* __restrict__ xyz,
                                                             const float* __restrict__ packed, int64_t P,
                                                             float4* __restrict__ raw, float* __restrict__ pe_out,
-                                                            float* __restrict__ acts) {
+                                                            float* __restrict__ acts, const int* __restrict__ idx,
+                                                            const int* __restrict__ count) {
     const int lane = threadIdx.x & 63;
     const int h = lane >> 5;
-    const int64_t sample = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 32 + (lane & 31);
-    const int64_t sidx = sample < P ? sample : P - 1;
+    if (idx != nullptr) {                     // sparse launch (hnrf_compact_samples): waves are independent
+        P = *count;
+        if (((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 32 >= P) return;
+    }
+    const int64_t slot = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 32 + (lane & 31);
+    const int64_t sclamp = slot < P ? slot : P - 1;
+    const int64_t sidx = idx ? (int64_t)idx[sclamp] : sclamp;
+    const int64_t sample = slot < P ? sidx : P;
     const float x[3] = {xyz[sidx * 3 + 0], xyz[sidx * 3 + 1], xyz[sidx * 3 + 2]};
 
     // positional encoding in B-operand order (see pe_col): 32 K-steps
@@ -223,7 +230,7 @@ __global__ __launch_bounds__(256) void canonical_f32_kernel(const float* __restr
     pe[30] = h ? x[1] : x[0];
     pe[31] = h ? 0.f : x[2];
     float* save = nullptr;                       // this lane's activation row (advances one layer per step)
-    if (SAVE && sample < P) {
+    if (SAVE && slot < P) {
         save = acts + sample * 256;
 #pragma unroll
         for (int j = 0; j < 32; ++j) {
@@ -267,7 +274,7 @@ __global__ __launch_bounds__(256) void canonical_f32_kernel(const float* __restr
     float o[16];
     mlp_layer<1, 0, 32, true, false>(wptr, ring, bias, none, hA, o);
     // rows 0..3 of the head tile live in registers 0..3 of the lower lane half
-    if (h == 0 && sample < P) raw[sample] = make_float4(o[0], o[1], o[2], o[3]);
+    if (h == 0 && slot < P) raw[sample] = make_float4(o[0], o[1], o[2], o[3]);
 }
 
 // K2.  Same structure, width 128.  SAVE: pe_out [P,36], acts [6][P][128].
@@ -276,11 +283,18 @@ __global__ __launch_bounds__(256) void nonrigid_f32_kernel(const float* __restri
                                                            const float* __restrict__ hann_w,
                                                            const float* __restrict__ packed, int64_t P,
                                                            float* __restrict__ xyz, float* __restrict__ offsets,
-                                                           float* __restrict__ pe_out, float* __restrict__ acts) {
+                                                           float* __restrict__ pe_out, float* __restrict__ acts,
+                                                           const int* __restrict__ idx, const int* __restrict__ count) {
     const int lane = threadIdx.x & 63;
     const int h = lane >> 5;
-    const int64_t sample = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 32 + (lane & 31);
-    const int64_t sidx = sample < P ? sample : P - 1;
+    if (idx != nullptr) {
+        P = *count;
+        if (((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 32 >= P) return;
+    }
+    const int64_t slot = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 32 + (lane & 31);
+    const int64_t sclamp = slot < P ? slot : P - 1;
+    const int64_t sidx = idx ? (int64_t)idx[sclamp] : sclamp;
+    const int64_t sample = slot < P ? sidx : P;
     const float x[3] = {x_skel[sidx * 3 + 0], x_skel[sidx * 3 + 1], x_skel[sidx * 3 + 2]};
 
     float pe[20];
@@ -296,7 +310,7 @@ __global__ __launch_bounds__(256) void nonrigid_f32_kernel(const float* __restri
     pe[18] = 0.f;
     pe[19] = 0.f;
     float* save = nullptr;
-    if (SAVE && sample < P) {
+    if (SAVE && slot < P) {
         save = acts + sample * 128;
 #pragma unroll
         for (int j = 0; j < 18; ++j) pe_out[sample * 36 + pe_col(PE_NONRIGID, j, h)] = pe[j];
@@ -328,7 +342,7 @@ __global__ __launch_bounds__(256) void nonrigid_f32_kernel(const float* __restri
     bias += 128;
     float o[16];
     mlp_layer<1, 0, 16, true, false>(wptr, ring, bias, none, hA, o);
-    if (h == 0 && sample < P) {
+    if (h == 0 && slot < P) {
         xyz[sample * 3 + 0] = x[0] + o[0];
         xyz[sample * 3 + 1] = x[1] + o[1];
         xyz[sample * 3 + 2] = x[2] + o[2];
@@ -430,18 +444,25 @@ extern "C" int hnrf_nonrigid_pack(const float* const* weights, const float* cons
     return launch_pack(d, cond, out, st);
 }
 
+extern "C" int hnrf_canonical_fwd_sparse(const float* xyz, const void* packed, int mode, int64_t P, const int* idx,
+                                         const int* count, float* raw, void* stream);
 extern "C" int hnrf_canonical_fwd(const float* xyz, const void* packed, int mode, int64_t P, float* raw,
                                   void* stream) {
+    return hnrf_canonical_fwd_sparse(xyz, packed, mode, P, nullptr, nullptr, raw, stream);
+}
+extern "C" int hnrf_canonical_fwd_sparse(const float* xyz, const void* packed, int mode, int64_t P, const int* idx,
+                                         const int* count, float* raw, void* stream) {
     HNRF_REQUIRE(xyz && packed && raw, HNRF_E_ARG, "hnrf_canonical_fwd: null pointer");
+    HNRF_REQUIRE((idx == nullptr) == (count == nullptr), HNRF_E_ARG, "hnrf_canonical_fwd: idx and count go together");
     HNRF_REQUIRE(mode == HNRF_MLP_F32 || mode == HNRF_MLP_F16X3, HNRF_E_UNSUPPORTED,
                  "hnrf_canonical_fwd: mode %d not built", mode);
     HNRF_REQUIRE(P >= 0 && (P + 127) / 128 < 2147483647LL, HNRF_E_ARG, "hnrf_canonical_fwd: bad P=%lld", (long long)P);
     HNRF_REQUIRE((((uintptr_t)packed | (uintptr_t)raw) & 15) == 0, HNRF_E_ARG,
                  "hnrf_canonical_fwd: packed/raw must be 16-byte aligned");
     if (P == 0) return HNRF_OK;
-    if (mode == HNRF_MLP_F16X3) return canonical16_fwd(xyz, packed, P, raw, (hipStream_t)stream);
+    if (mode == HNRF_MLP_F16X3) return canonical16_fwd(xyz, packed, P, raw, idx, count, (hipStream_t)stream);
     hipLaunchKernelGGL(canonical_f32_kernel<false>, dim3((unsigned)((P + 127) / 128)), dim3(256), 0,
-                       (hipStream_t)stream, xyz, (const float*)packed, P, (float4*)raw, nullptr, nullptr);
+                       (hipStream_t)stream, xyz, (const float*)packed, P, (float4*)raw, nullptr, nullptr, idx, count);
     return check_launch("hnrf_canonical_fwd");
 }
 
@@ -455,21 +476,31 @@ extern "C" int hnrf_canonical_fwd_train(const float* xyz, const void* packed, in
                  "hnrf_canonical_fwd_train: packed/raw/acts must be 16-byte aligned");
     if (P == 0) return HNRF_OK;
     hipLaunchKernelGGL(canonical_f32_kernel<true>, dim3((unsigned)((P + 127) / 128)), dim3(256), 0,
-                       (hipStream_t)stream, xyz, (const float*)packed, P, (float4*)raw, pe_out, acts);
+                       (hipStream_t)stream, xyz, (const float*)packed, P, (float4*)raw, pe_out, acts, nullptr, nullptr);
     return check_launch("hnrf_canonical_fwd_train");
 }
 
+extern "C" int hnrf_nonrigid_fwd_sparse(const float* x_skel, const float* hann_w, const void* packed, int mode,
+                                        int64_t P, const int* idx, const int* count, float* xyz, float* offsets,
+                                        void* stream);
 extern "C" int hnrf_nonrigid_fwd(const float* x_skel, const float* hann_w, const void* packed, int mode, int64_t P,
                                  float* xyz, float* offsets, void* stream) {
+    return hnrf_nonrigid_fwd_sparse(x_skel, hann_w, packed, mode, P, nullptr, nullptr, xyz, offsets, stream);
+}
+extern "C" int hnrf_nonrigid_fwd_sparse(const float* x_skel, const float* hann_w, const void* packed, int mode,
+                                        int64_t P, const int* idx, const int* count, float* xyz, float* offsets,
+                                        void* stream) {
     HNRF_REQUIRE(x_skel && hann_w && packed && xyz, HNRF_E_ARG, "hnrf_nonrigid_fwd: null pointer");
+    HNRF_REQUIRE((idx == nullptr) == (count == nullptr), HNRF_E_ARG, "hnrf_nonrigid_fwd: idx and count go together");
     HNRF_REQUIRE(mode == HNRF_MLP_F32 || mode == HNRF_MLP_F16X3, HNRF_E_UNSUPPORTED,
                  "hnrf_nonrigid_fwd: mode %d not built", mode);
     HNRF_REQUIRE(P >= 0 && (P + 127) / 128 < 2147483647LL, HNRF_E_ARG, "hnrf_nonrigid_fwd: bad P=%lld", (long long)P);
     HNRF_REQUIRE(((uintptr_t)packed & 15) == 0, HNRF_E_ARG, "hnrf_nonrigid_fwd: packed must be 16-byte aligned");
     if (P == 0) return HNRF_OK;
-    if (mode == HNRF_MLP_F16X3) return nonrigid16_fwd(x_skel, hann_w, packed, P, xyz, offsets, (hipStream_t)stream);
+    if (mode == HNRF_MLP_F16X3)
+        return nonrigid16_fwd(x_skel, hann_w, packed, P, xyz, offsets, idx, count, (hipStream_t)stream);
     hipLaunchKernelGGL(nonrigid_f32_kernel<false>, dim3((unsigned)((P + 127) / 128)), dim3(256), 0,
-                       (hipStream_t)stream, x_skel, hann_w, (const float*)packed, P, xyz, offsets, nullptr, nullptr);
+                       (hipStream_t)stream, x_skel, hann_w, (const float*)packed, P, xyz, offsets, nullptr, nullptr, idx, count);
     return check_launch("hnrf_nonrigid_fwd");
 }
 
@@ -485,6 +516,6 @@ extern "C" int hnrf_nonrigid_fwd_train(const float* x_skel, const float* hann_w,
                  "hnrf_nonrigid_fwd_train: packed/acts must be 16-byte aligned");
     if (P == 0) return HNRF_OK;
     hipLaunchKernelGGL(nonrigid_f32_kernel<true>, dim3((unsigned)((P + 127) / 128)), dim3(256), 0,
-                       (hipStream_t)stream, x_skel, hann_w, (const float*)packed, P, xyz, offsets, pe_out, acts);
+                       (hipStream_t)stream, x_skel, hann_w, (const float*)packed, P, xyz, offsets, pe_out, acts, nullptr, nullptr);
     return check_launch("hnrf_nonrigid_fwd_train");
 }

@@ -418,12 +418,20 @@ __device__ __forceinline__ void stash_pe(const Pipe& p, int ks, const float (&v)
 // K3, f16x3.  grid = ceil(P / 128) workgroups of 4 waves x 32 samples; LDS = 160 KiB.
 __global__ __launch_bounds__(256) void canonical_f16x3_kernel(const float* __restrict__ xyz,
                                                               const char* __restrict__ packed, int64_t P,
-                                                              float4* __restrict__ raw) {
+                                                              float4* __restrict__ raw, const int* __restrict__ idx,
+                                                              const int* __restrict__ count) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    // sparse launch: only the `*count` samples listed in idx are evaluated (hnrf_compact_samples)
+    if (idx != nullptr) {
+        P = *count;
+        if ((int64_t)blockIdx.x * 128 >= P) return;           // whole workgroup, before any DMA / barrier
+    }
     Pipe p = pipe_start(packed, CNL16_BIAS, CNL16_BIAS_LDS, CNL16_SLAB, 4 * CNL16_NB_L0, 4 * CNL16_NB_L0, smem);
     const int lane = threadIdx.x & 63, h = lane >> 5;
-    const int64_t sample = ((int64_t)blockIdx.x * 4 + p.wave) * 32 + (lane & 31);
-    const int64_t sidx = sample < P ? sample : P - 1;
+    const int64_t slot = ((int64_t)blockIdx.x * 4 + p.wave) * 32 + (lane & 31);
+    const int64_t sclamp = slot < P ? slot : P - 1;
+    const int64_t sidx = idx ? (int64_t)idx[sclamp] : sclamp;
+    const int64_t sample = slot < P ? sidx : P;               // P = "do not store"
 
     // positional encoding -> LDS stash, while the first slabs fly
     const float x[3] = {xyz[sidx * 3 + 0], xyz[sidx * 3 + 1], xyz[sidx * 3 + 2]};
@@ -469,7 +477,7 @@ __global__ __launch_bounds__(256) void canonical_f16x3_kernel(const float* __res
     h16x8 dh[2], dl[2];
     layer16<1, 1, 0, 16, false>(p, 0, 0, hA_h, hA_l, dh, dl, last);
     const float* ob = reinterpret_cast<const float*>(packed + CNL16_BIAS + CNL16_BIAS_LDS);   // head bias: scalar loads
-    if (h == 0 && sample < P) raw[sample] = make_float4(last[0] + ob[0], last[1] + ob[1], last[2] + ob[2], last[3] + ob[3]);
+    if (h == 0 && slot < P) raw[sample] = make_float4(last[0] + ob[0], last[1] + ob[1], last[2] + ob[2], last[3] + ob[3]);
 #ifdef HNRF_STAMP
     if (threadIdx.x == 0 && blockIdx.x < 4096) {   // stamps leave through a buffer nothing else reads
         const unsigned long long te = __builtin_readcyclecounter();
@@ -483,12 +491,20 @@ __global__ __launch_bounds__(256) void canonical_f16x3_kernel(const float* __res
 __global__ __launch_bounds__(256) void nonrigid_f16x3_kernel(const float* __restrict__ x_skel,
                                                              const float* __restrict__ hann_w,
                                                              const char* __restrict__ packed, int64_t P,
-                                                             float* __restrict__ xyz, float* __restrict__ offsets) {
+                                                             float* __restrict__ xyz, float* __restrict__ offsets,
+                                                             const int* __restrict__ idx,
+                                                             const int* __restrict__ count) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    if (idx != nullptr) {
+        P = *count;
+        if ((int64_t)blockIdx.x * 128 >= P) return;
+    }
     Pipe p = pipe_start(packed, NR16_BIAS, NR16_BIAS_LDS, NR16_SLAB, 4 * NR16_NB_L0, NR16_NB_MID, smem);
     const int lane = threadIdx.x & 63, h = lane >> 5;
-    const int64_t sample = ((int64_t)blockIdx.x * 4 + p.wave) * 32 + (lane & 31);
-    const int64_t sidx = sample < P ? sample : P - 1;
+    const int64_t slot = ((int64_t)blockIdx.x * 4 + p.wave) * 32 + (lane & 31);
+    const int64_t sclamp = slot < P ? slot : P - 1;
+    const int64_t sidx = idx ? (int64_t)idx[sclamp] : sclamp;
+    const int64_t sample = slot < P ? sidx : P;
 
     const float x[3] = {x_skel[sidx * 3 + 0], x_skel[sidx * 3 + 1], x_skel[sidx * 3 + 2]};
     float pev[32];
@@ -526,7 +542,7 @@ __global__ __launch_bounds__(256) void nonrigid_f16x3_kernel(const float* __rest
     h16x8 dh[2], dl[2];
     layer16<1, 1, 0, 8, false>(p, 0, 0, hA_h, hA_l, dh, dl, last);
     const float* ob = reinterpret_cast<const float*>(packed + NR16_BIAS + NR16_BIAS_LDS);
-    if (h == 0 && sample < P) {
+    if (h == 0 && slot < P) {
         const float o0 = last[0] + ob[0], o1 = last[1] + ob[1], o2 = last[2] + ob[2];
         xyz[sample * 3 + 0] = x[0] + o0;
         xyz[sample * 3 + 1] = x[1] + o1;
@@ -596,7 +612,8 @@ int nonrigid16_pack(const float* const* w, const float* const* b, const float* c
     return launch_pack16(d, cond, out, st);
 }
 
-int canonical16_fwd(const float* xyz, const void* packed, int64_t P, float* raw, hipStream_t st) {
+int canonical16_fwd(const float* xyz, const void* packed, int64_t P, float* raw, const int* idx, const int* count,
+                    hipStream_t st) {
     constexpr int lds = CNL16_BIAS_LDS + PE_STASH + RING * CNL16_SLAB;
     static bool attr_set = false;
     if (!attr_set) {
@@ -608,12 +625,12 @@ int canonical16_fwd(const float* xyz, const void* packed, int64_t P, float* raw,
         attr_set = true;
     }
     hipLaunchKernelGGL(canonical_f16x3_kernel, dim3((unsigned)((P + 127) / 128)), dim3(256), lds, st, xyz,
-                       (const char*)packed, P, (float4*)raw);
+                       (const char*)packed, P, (float4*)raw, idx, count);
     return check_launch("hnrf_canonical_fwd (f16x3)");
 }
 
 int nonrigid16_fwd(const float* x_skel, const float* hann_w, const void* packed, int64_t P, float* xyz,
-                   float* offsets, hipStream_t st) {
+                   float* offsets, const int* idx, const int* count, hipStream_t st) {
     constexpr int lds = NR16_BIAS_LDS + PE_STASH + RING * NR16_SLAB;
     static bool attr_set = false;
     if (!attr_set) {
@@ -625,7 +642,7 @@ int nonrigid16_fwd(const float* x_skel, const float* hann_w, const void* packed,
         attr_set = true;
     }
     hipLaunchKernelGGL(nonrigid_f16x3_kernel, dim3((unsigned)((P + 127) / 128)), dim3(256), lds, st, x_skel, hann_w,
-                       (const char*)packed, P, xyz, offsets);
+                       (const char*)packed, P, xyz, offsets, idx, count);
     return check_launch("hnrf_nonrigid_fwd (f16x3)");
 }
 

@@ -109,7 +109,43 @@ __global__ __launch_bounds__(256) void sample_warp_kernel(
     fg_mask[p] = wsum;
 }
 
+// Stream compaction of the samples worth evaluating: idx[0..count) = indices p with fg_mask[p] >= eps.
+// A sample with fg_mask < eps has alpha < eps (alpha = (1-exp(..)) * fg_mask), so dropping it changes a
+// ray's rgb / alpha / depth by at most ~2 S eps (own weight + its effect on later transmittances);
+// eps = 0 keeps everything.  Order: block-contiguous runs, blocks in arrival order (irrelevant to the MLPs).
+__global__ __launch_bounds__(256) void compact_kernel(const float* __restrict__ fg_mask, float eps, int64_t P,
+                                                      int* __restrict__ idx, int* __restrict__ count) {
+    __shared__ int wave_tot[4];
+    __shared__ int block_base;
+    const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const bool keep = p < P && fg_mask[p] >= eps;
+    const unsigned long long bal = __ballot(keep);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int before = __popcll(bal & ((1ull << lane) - 1ull));
+    if (lane == 0) wave_tot[wave] = __popcll(bal);
+    __syncthreads();
+    if (threadIdx.x == 0) block_base = atomicAdd(count, wave_tot[0] + wave_tot[1] + wave_tot[2] + wave_tot[3]);
+    __syncthreads();
+    int off = block_base + before;
+    for (int w = 0; w < wave; ++w) off += wave_tot[w];
+    if (keep) idx[off] = (int)p;
+}
+
 }  // namespace hnrf
+
+extern "C" int hnrf_compact_samples(const float* fg_mask, float eps, int64_t P, int* idx, int* count, void* stream) {
+    using namespace hnrf;
+    HNRF_REQUIRE(fg_mask && idx && count, HNRF_E_ARG, "hnrf_compact_samples: null pointer");
+    HNRF_REQUIRE(P >= 0 && P < 2147483647LL, HNRF_E_ARG, "hnrf_compact_samples: bad P");
+    hipStream_t st = (hipStream_t)stream;
+    if (hipMemsetAsync(count, 0, sizeof(int), st) != hipSuccess) {
+        set_error("hnrf_compact_samples: memset failed");
+        return HNRF_E_LAUNCH;
+    }
+    if (P == 0) return HNRF_OK;
+    hipLaunchKernelGGL(compact_kernel, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, st, fg_mask, eps, P, idx, count);
+    return check_launch("hnrf_compact_samples");
+}
 
 extern "C" int hnrf_sample_warp_fwd(const float* rays_o, const float* rays_d,
                                     const float* near, const float* far, const float* t_rand,

@@ -398,7 +398,8 @@ class Network(nn.Module):
                 self.mlp_event_log.append(events)
             return ops.render_rays(rays_o, rays_d, near, far, t_rand, motion_Rs, motion_Ts, vol, bbox_min,
                                    bbox_scale, hann_w, nr_packed, cnl_packed, bg, S, mode,
-                                   workspace=self._workspace, mlp_events=events)
+                                   workspace=self._workspace, mlp_events=events,
+                                   cull_eps=float(amd_option('cull_eps', 0.0)))
         z, x_skel, mask, bmw = ops.sample_warp(rays_o, rays_d, near, far, t_rand, motion_Rs, motion_Ts, vol,
                                                bbox_min, bbox_scale, S, want_bmw=True)
         if nr_packed is not None:

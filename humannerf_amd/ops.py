@@ -123,7 +123,7 @@ def canonical(xyz, packed, mode='f32'):
     return raw
 
 
-def composite(raw, fg_mask, z_vals, rays_d, xyz, bgcolor, diagnostics=True):
+def composite(raw, fg_mask, z_vals, rays_d, xyz, bgcolor, diagnostics=True, cull_eps=0.0):
     """K4 (network.py:355-388).  Returns dict with rgb/alpha/depth and, when
     ``diagnostics``, weights_on_rays, rgb_on_rays, cnl_xyz, cnl_rgb, cnl_weight."""
     lib = _lib.load()
@@ -138,7 +138,7 @@ def composite(raw, fg_mask, z_vals, rays_d, xyz, bgcolor, diagnostics=True):
                    cnl_weight=torch.empty(R, device=dev))
     g = out.get
     _lib.check(lib.hnrf_composite_fwd(_ptr(raw), _ptr(fg_mask), _ptr(z_vals), _ptr(rays_d), _ptr(xyz),
-                                      _ptr(bgcolor), R, S, _ptr(out['rgb']), _ptr(out['alpha']),
+                                      _ptr(bgcolor), R, S, float(cull_eps), _ptr(out['rgb']), _ptr(out['alpha']),
                                       _ptr(out['depth']), _ptr(g('weights_on_rays')), _ptr(g('rgb_on_rays')),
                                       _ptr(g('cnl_xyz')), _ptr(g('cnl_rgb')), _ptr(g('cnl_weight')), _stream()),
                'hnrf_composite_fwd')
@@ -151,7 +151,7 @@ def render_workspace_bytes(R, S):
 
 def render_rays(rays_o, rays_d, near, far, t_rand, motion_Rs, motion_Ts, vol, bbox_min, bbox_scale,
                 hann_w, nr_packed, cnl_packed, bgcolor, n_samples, mode='f32', workspace=None, out=None,
-                mlp_events=None):
+                mlp_events=None, cull_eps=0.0):
     """The whole path for one ray chunk (network.py:474-602) with only the
     rgb/alpha/depth outputs; intermediates live in ``workspace``.  ``mlp_events``:
     optional pair of torch.cuda.Event(enable_timing=True), recorded around the
@@ -178,7 +178,7 @@ def render_rays(rays_o, rays_d, near, far, t_rand, motion_Rs, motion_Ts, vol, bb
     _lib.check(lib.hnrf_render_rays_fwd(_ptr(rays_o), _ptr(rays_d), _ptr(near), _ptr(far), _ptr(t_rand),
                                         _ptr(motion_Rs), _ptr(motion_Ts), _ptr(vol), _ptr(bbox_min),
                                         _ptr(bbox_scale), _ptr(hann_w), _ptr(nr_packed), _ptr(cnl_packed),
-                                        _ptr(bgcolor), MLP_MODES[mode], R, S, motion_Rs.shape[0], vol.shape[-1],
+                                        _ptr(bgcolor), MLP_MODES[mode], float(cull_eps), R, S, motion_Rs.shape[0], vol.shape[-1],
                                         _ptr(workspace), workspace.numel() * workspace.element_size(),
                                         _ptr(out['rgb']), _ptr(out['alpha']), _ptr(out['depth']),
                                         ev[0], ev[1], _stream()),
@@ -254,3 +254,37 @@ def sample_warp_bwd(rays_o, rays_d, z_vals, motion_Rs, motion_Ts, vol, bbox_min,
                                         _ptr(g_x_skel), _ptr(g_mask), R, S, B, G, _ptr(d_vol), _ptr(d_Rs), _ptr(d_Ts),
                                         _stream()), 'hnrf_sample_warp_bwd')
     return d_vol, d_Rs, d_Ts
+
+
+# ----------------------------------------------------------------------------- sample culling
+def compact_samples(fg_mask, eps):
+    """idx (P,) int32 and count (1,) int32 (device): samples with fg_mask >= eps."""
+    lib = _lib.load()
+    _chk(fg_mask)
+    P = fg_mask.numel()
+    idx = torch.empty(P, dtype=torch.int32, device=fg_mask.device)
+    count = torch.empty(1, dtype=torch.int32, device=fg_mask.device)
+    _lib.check(lib.hnrf_compact_samples(_ptr(fg_mask), float(eps), P, _ptr(idx), _ptr(count), _stream()),
+               'hnrf_compact_samples')
+    return idx, count
+
+
+def canonical_sparse(xyz, packed, idx, count, mode='f32', raw=None):
+    lib = _lib.load()
+    _chk(xyz, packed)
+    P = xyz.numel() // 3
+    if raw is None:
+        raw = torch.zeros(*xyz.shape[:-1], 4, device=xyz.device)
+    _lib.check(lib.hnrf_canonical_fwd_sparse(_ptr(xyz), _ptr(packed), MLP_MODES[mode], P, _ptr(idx), _ptr(count),
+                                             _ptr(raw), _stream()), 'hnrf_canonical_fwd_sparse')
+    return raw
+
+
+def nonrigid_sparse(x_skel, hann_w, packed, idx, count, mode='f32'):
+    lib = _lib.load()
+    _chk(x_skel, hann_w, packed)
+    P = x_skel.numel() // 3
+    xyz = x_skel.clone()
+    _lib.check(lib.hnrf_nonrigid_fwd_sparse(_ptr(x_skel), _ptr(hann_w), _ptr(packed), MLP_MODES[mode], P, _ptr(idx),
+                                            _ptr(count), _ptr(xyz), 0, _stream()), 'hnrf_nonrigid_fwd_sparse')
+    return xyz

@@ -58,6 +58,13 @@ int hnrf_sample_warp_fwd(const float* rays_o, const float* rays_d,
                          float* z_vals, float* x_skel, float* fg_mask, float* bmw,
                          void* stream);
 
+/* ---- sample culling (no counterpart in the reference, which evaluates every sample) --------
+ * idx[0 .. *count) = indices p with fg_mask[p] >= eps, count written on the device (no host
+ * sync).  alpha = (1 - exp(-sigma delta)) * fg_mask (network.py:369) < eps for a dropped sample,
+ * so a ray's rgb / alpha / depth move by at most ~2 S eps; eps == 0 keeps every sample and the
+ * path is exactly the reference's.  idx must hold P ints. */
+int hnrf_compact_samples(const float* fg_mask, float eps, int64_t P, int* idx, int* count, void* stream);
+
 /* ---- K2: non-rigid motion MLP ---------------------------------------------
  * Replaces hannw_fourier embed (embedders/hannw_fourier.py:21-49) +
  * NonRigidMotionMLP.forward (non_rigid_motion_mlps/mlp_offset.py:74-114) as
@@ -77,6 +84,9 @@ int hnrf_nonrigid_pack(const float* const* weights, const float* const* biases,
  *  26-40).  Outputs xyz = x_skel + offset [P,3]; offsets [P,3] or NULL. */
 int hnrf_nonrigid_fwd(const float* x_skel, const float* hann_w, const void* packed,
                       int mode, int64_t P, float* xyz, float* offsets, void* stream);
+int hnrf_nonrigid_fwd_sparse(const float* x_skel, const float* hann_w, const void* packed,
+                             int mode, int64_t P, const int* idx, const int* count,
+                             float* xyz, float* offsets, void* stream);
 
 /* ---- K3: canonical MLP ----------------------------------------------------
  * Replaces fourier embed (embedders/fourier.py:9-38) + CanonicalMLP.forward
@@ -90,16 +100,23 @@ int hnrf_canonical_pack(const float* const* weights, const float* const* biases,
 /*  xyz [P,3] -> raw [P,4] = (r,g,b,sigma) pre-activation. */
 int hnrf_canonical_fwd(const float* xyz, const void* packed, int mode, int64_t P,
                        float* raw, void* stream);
+/*  Sparse form: only the samples idx[0 .. *count) are evaluated (xyz read at and raw written to
+ *  those indices; everything else untouched).  idx, count: device pointers from
+ *  hnrf_compact_samples; P = capacity of idx (grid size). */
+int hnrf_canonical_fwd_sparse(const float* xyz, const void* packed, int mode, int64_t P,
+                              const int* idx, const int* count, float* raw, void* stream);
 
 /* ---- K4: alpha compositing --------------------------------------------------
  * Replaces Network._raw2outputs (network.py:355-388).
  *  raw [R,S,4]; fg_mask [R,S]; z_vals [R,S]; rays_d [R,3]; xyz [R,S,3] (may be
  *  NULL when cnl_xyz is NULL); bgcolor [3] in 0..255 (device pointer).
+ *  cull_eps: samples with fg_mask < cull_eps get weight 0 and their raw is not interpreted
+ *  (0 = reference behaviour).
  * Outputs: rgb [R,3], alpha [R], depth [R]; nullable: weights [R,S],
  *  rgb_on_rays [R,S,3], cnl_xyz [R,3], cnl_rgb [R,3], cnl_weight [R]. */
 int hnrf_composite_fwd(const float* raw, const float* fg_mask, const float* z_vals,
                        const float* rays_d, const float* xyz, const float* bgcolor,
-                       int64_t R, int S,
+                       int64_t R, int S, float cull_eps,
                        float* rgb, float* alpha, float* depth,
                        float* weights, float* rgb_on_rays,
                        float* cnl_xyz, float* cnl_rgb, float* cnl_weight,
@@ -110,6 +127,8 @@ int hnrf_composite_fwd(const float* raw, const float* fg_mask, const float* z_va
  * `stream`, intermediates in caller-provided workspace
  * (hnrf_render_workspace_bytes(R,S) bytes, 256-byte aligned).
  * nr_packed == NULL means cfg.ignore_non_rigid_motions (network.py:264,276-277).
+ * cull_eps > 0: the MLPs run only on the samples with fg_mask >= cull_eps (see
+ * hnrf_compact_samples); 0 = every sample, as the reference.
  * Only rgb/alpha/depth are written (the trainer and the image writers read
  * nothing else: trainer.py:121, run.py:130).
  * ev_mlp_start / ev_mlp_stop: optional hipEvent_t (as void*, may be NULL) recorded
@@ -121,7 +140,7 @@ int hnrf_render_rays_fwd(const float* rays_o, const float* rays_d,
                          const float* motion_Rs, const float* motion_Ts,
                          const float* vol, const float* bbox_min, const float* bbox_scale,
                          const float* hann_w, const void* nr_packed, const void* cnl_packed,
-                         const float* bgcolor, int mode,
+                         const float* bgcolor, int mode, float cull_eps,
                          int64_t R, int S, int B, int G,
                          void* workspace, size_t workspace_bytes,
                          float* rgb, float* alpha, float* depth,

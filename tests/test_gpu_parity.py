@@ -287,3 +287,35 @@ def test_full_size_properties():
     empty = ops.render_rays(o, d, nr, fa, None, Rs, Ts, torch.zeros_like(vol), *args[3:])
     assert float(empty['alpha'].abs().max()) == 0
     assert torch.allclose(empty['rgb'], (bg / 255.).expand(R, 3))
+
+
+def test_sample_culling(gpu_net, golden_frame):
+    """Opt-in culling (cfg.amd.cull_eps): eps = 0 is bit-identical to the dense path; eps > 0 stays
+    inside the proven bound 2 * S * eps and drops a large share of the samples."""
+    from humannerf_amd import config, ops
+    cfg = config.cfg
+    cfg.perturb, cfg.amd.diagnostics = 0., False
+    S = 128
+    try:
+        for mode in ('f16x3', 'f32'):
+            cfg.amd.mlp_mode = mode
+            with torch.no_grad():
+                cfg.amd.cull_eps = 0.0
+                dense = gpu_net(**frame_to_gpu(golden_frame), iter_val=1e7)
+                for eps in (1e-9, 1e-7):
+                    cfg.amd.cull_eps = eps
+                    culled = gpu_net(**frame_to_gpu(golden_frame), iter_val=1e7)
+                    for k in ('rgb', 'alpha'):
+                        err = float((culled[k] - dense[k]).abs().max())
+                        assert err <= 2 * S * eps + 1e-7, (mode, eps, k, err)
+                    assert float((culled['depth'] - dense['depth']).abs().max()) <= (2 * S * eps + 1e-7) * 10
+    finally:
+        cfg.amd.cull_eps, cfg.amd.mlp_mode, cfg.amd.diagnostics, cfg.perturb = 0.0, 'f16x3', True, 1.0
+    # the compaction itself: exact index set, count on the device
+    rs = np.random.RandomState(0)
+    m = rs.uniform(0, 1e-6, 100003).astype(np.float32)
+    m[::7] = 0
+    idx, count = ops.compact_samples(torch.from_numpy(m).to(dev()), 2e-7)
+    n = int(count.item())
+    want = np.nonzero(m >= 2e-7)[0]
+    assert n == len(want) and np.array_equal(np.sort(idx[:n].cpu().numpy()), want)
