@@ -54,12 +54,18 @@ def main():
     world = int(os.environ.get('WORLD_SIZE', 1))
     assert world == args.gpus or world == 1, (world, args.gpus)
     assert torch.cuda.is_available(), 'bench.py needs an MI355X'
+    if 'HNRF_BENCH_DEVICE' in os.environ:          # rehearsal of the N-rank path on a 1-GPU box (with gloo)
+        local_rank = int(os.environ['HNRF_BENCH_DEVICE'])
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+        backend = os.environ.get('HNRF_DIST_BACKEND', 'nccl')          # 'nccl' IS RCCL on ROCm
+        if backend == 'nccl':
+            dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     from humannerf_amd import scene
     from humannerf_amd.config import cfg
