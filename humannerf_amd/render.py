@@ -1,0 +1,86 @@
+"""Frame-sharded rendering driver around the hot path ("next" row).
+
+What run.py does per frame (run.py:68-157, 214-445): ``model(**data, iter_val=cfg.eval_iter)`` under
+no_grad, scatter the rendered rays back into the H x W image by ``ray_mask`` with background fill
+(run.py:48-65), quantise to 8 bit, write.  Here the scatter / quantisation runs on the GPU, frames are
+dealt round-robin over the ranks (one process per GPU, no data-path collective) and the finished
+uint8 images travel to the host asynchronously; rank 0 can gather them in frame order.
+"""
+import numpy as np
+import torch
+
+from . import dist as hdist
+from .config import cfg
+
+
+def unpack_to_image(width, height, ray_mask, bgcolor, rgb, alpha):
+    """Device-side restatement of run.py:48-65: returns (rgb uint8 (H,W,3), alpha uint8 (H,W,3)).
+    bgcolor in 0..1 like the reference's call sites pass it (run.py:127-131)."""
+    dev = rgb.device
+    img = torch.as_tensor(bgcolor, dtype=torch.float32, device=dev).reshape(1, 3).repeat(height * width, 1)
+    img[ray_mask] = rgb
+    amap = torch.zeros(height * width, dtype=torch.float32, device=dev)
+    amap[ray_mask] = alpha
+    to8 = lambda x: (255.0 * x.clamp(0.0, 1.0)).to(torch.uint8)          # image_util.to_8b_image
+    rgb8 = to8(img).reshape(height, width, 3)
+    a8 = to8(amap).reshape(height, width, 1).expand(height, width, 3).contiguous()
+    return rgb8, a8
+
+
+def psnr(pred, target):
+    """-10 log10(mse), maximum pixel value 1 (metrics_util.py:78-88)."""
+    mse = ((pred - target) ** 2).mean()
+    return -10.0 * torch.log(mse) / np.log(10.0)
+
+
+def render_frames(network, frames, rank=0, world=1, device=None, on_image=None):
+    """Render ``frames`` (sequence of per-frame input dicts, numpy or tensors) frame-sharded.
+
+    Returns {frame_idx: uint8 rgb image on the host} for this rank's frames.  ``on_image(idx, rgb8,
+    alpha8)`` is called as images arrive (e.g. a PNG writer thread)."""
+    device = device or next(network.parameters()).device
+    network.eval()
+    keys = ('rays', 'near', 'far', 'dst_Rs', 'dst_Ts', 'cnl_gtfms', 'motion_weights_priors', 'dst_posevec',
+            'cnl_bbox_min_xyz', 'cnl_bbox_scale_xyz', 'bgcolor')
+    old = cfg.perturb
+    cfg.perturb = 0.                                                     # run.py:71,215
+    out = {}
+    copy_stream = torch.cuda.Stream(device=device) if device.type == 'cuda' else None
+    pending = []
+    try:
+        for idx in hdist.frame_shard(len(frames), rank, world):
+            fr = frames[idx]
+            data = {k: torch.as_tensor(np.ascontiguousarray(fr[k]) if isinstance(fr[k], np.ndarray) else fr[k]).to(device)
+                    for k in keys}
+            with torch.no_grad():
+                res = network(**data, iter_val=float(cfg.eval_iter))
+            mask = torch.as_tensor(fr['ray_mask']).to(device)
+            rgb8, a8 = unpack_to_image(int(fr['img_width']), int(fr['img_height']), mask, data['bgcolor'] / 255.,
+                                       res['rgb'], res['alpha'])
+            if copy_stream is not None:                                  # overlap D2H with the next frame
+                copy_stream.wait_stream(torch.cuda.current_stream(device))
+                with torch.cuda.stream(copy_stream):
+                    host = (rgb8.to('cpu', non_blocking=True), a8.to('cpu', non_blocking=True))
+                    ev = torch.cuda.Event()
+                    ev.record(copy_stream)
+                rgb8.record_stream(copy_stream)
+                a8.record_stream(copy_stream)
+                pending.append((idx, host, ev))
+            else:
+                pending.append((idx, (rgb8.cpu(), a8.cpu()), None))
+            while pending and (pending[0][2] is None or pending[0][2].query() or len(pending) > 2):
+                i, (h_rgb, h_a), e = pending.pop(0)
+                if e is not None:
+                    e.synchronize()
+                out[i] = h_rgb.numpy()
+                if on_image is not None:
+                    on_image(i, out[i], h_a.numpy())
+        for i, (h_rgb, h_a), e in pending:
+            if e is not None:
+                e.synchronize()
+            out[i] = h_rgb.numpy()
+            if on_image is not None:
+                on_image(i, out[i], h_a.numpy())
+    finally:
+        cfg.perturb = old
+    return out

@@ -319,3 +319,26 @@ def test_sample_culling(gpu_net, golden_frame):
     n = int(count.item())
     want = np.nonzero(m >= 2e-7)[0]
     assert n == len(want) and np.array_equal(np.sort(idx[:n].cpu().numpy()), want)
+
+
+def test_render_frames_driver(gpu_net):
+    """Frame-sharded driver: image scatter with background fill, 8-bit quantisation, frame order."""
+    from humannerf_amd import render, scene
+    from humannerf_amd.config import cfg
+    frames = [scene.synthetic_frame(H=48, W=48, focal_at_512=1250.0, pose_seed=s, bgcolor=(255., 255., 255.))
+              for s in range(3)]
+    cfg.amd.diagnostics = False
+    try:
+        imgs0 = render.render_frames(gpu_net, frames, rank=0, world=2)
+        imgs1 = render.render_frames(gpu_net, frames, rank=1, world=2)
+    finally:
+        cfg.amd.diagnostics = True
+    assert sorted(imgs0) == [0, 2] and sorted(imgs1) == [1]
+    for i, fr in enumerate(frames):
+        img = (imgs0 if i % 2 == 0 else imgs1)[i]
+        assert img.shape == (48, 48, 3) and img.dtype == np.uint8
+        miss = ~fr['ray_mask'].reshape(48, 48)
+        assert (img[miss] == 255).all()                      # background fill where no ray was cast
+        assert (img[~miss] < 255).any()
+    x = torch.rand(10, 3)
+    assert abs(float(render.psnr(x, x + 0.1)) - 20.0) < 1e-4
