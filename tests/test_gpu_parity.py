@@ -342,3 +342,42 @@ def test_render_frames_driver(gpu_net):
         assert (img[~miss] < 255).any()
     x = torch.rand(10, 3)
     assert abs(float(render.psnr(x, x + 0.1)) - 20.0) < 1e-4
+
+
+def test_ray_chunking_is_invisible(gpu_net, golden_frame):
+    """Network._batchify_rays (network.py:330-352): results do not depend on cfg.chunk, also when the
+    last chunk is ragged (144 rays in chunks of 50) and in the 11-output diagnostic path."""
+    from humannerf_amd.config import cfg
+    cfg.perturb = 0.
+    try:
+        with torch.no_grad():
+            cfg.chunk = 32768
+            one = gpu_net(**frame_to_gpu(golden_frame), iter_val=1e7)
+            cfg.chunk = 50
+            many = gpu_net(**frame_to_gpu(golden_frame), iter_val=1e7)
+    finally:
+        cfg.chunk, cfg.perturb = 32768, 1.0
+    assert set(one) == set(many) and len(one) == 11
+    for k in one:
+        assert torch.equal(one[k], many[k]), k
+
+
+def test_c5_sized_samples_per_ray(gpu_net, golden_frame):
+    """BASELINE config 5 uses 256 samples per ray: lean path == diagnostic path at S = 256, and the
+    denser sampling converges towards the S = 128 image (same integral)."""
+    from humannerf_amd.config import cfg
+    cfg.perturb = 0.
+    try:
+        with torch.no_grad():
+            cfg.N_samples = 256
+            full = gpu_net(**frame_to_gpu(golden_frame), iter_val=1e7)
+            cfg.amd.diagnostics = False
+            lean = gpu_net(**frame_to_gpu(golden_frame), iter_val=1e7)
+            cfg.N_samples = 128
+            s128 = gpu_net(**frame_to_gpu(golden_frame), iter_val=1e7)
+    finally:
+        cfg.N_samples, cfg.perturb, cfg.amd.diagnostics = 128, 1.0, True
+    assert full['weights_on_rays'].shape[-1] == 256
+    for k in lean:
+        assert torch.equal(lean[k], full[k])
+    assert float((full['alpha'] - s128['alpha']).abs().mean()) < 0.02
