@@ -499,7 +499,7 @@ __global__ __launch_bounds__(256) void nonrigid_f16x3_kernel(const float* __rest
         P = *count;
         if ((int64_t)blockIdx.x * 128 >= P) return;
     }
-    Pipe p = pipe_start(packed, NR16_BIAS, NR16_BIAS_LDS, NR16_SLAB, 4 * NR16_NB_L0, NR16_NB_MID, smem);
+    Pipe p = pipe_start(packed, NR16_BIAS, NR16_BIAS_LDS, NR16_SLAB, 4 * NR16_NB_L0, 2 * NR16_NB_MID, smem);
     const int lane = threadIdx.x & 63, h = lane >> 5;
     const int64_t slot = ((int64_t)blockIdx.x * 4 + p.wave) * 32 + (lane & 31);
     const int64_t sclamp = slot < P ? slot : P - 1;
@@ -529,16 +529,17 @@ __global__ __launch_bounds__(256) void nonrigid_f16x3_kernel(const float* __rest
 
     h16x8 hA_h[8], hA_l[8], hB_h[8], hB_l[8];
     float last[16];
-    layer16<4, 4, 4, 0, true>(p, 0 /*already in flight*/, NR16_NB_MID, hB_h, hB_l, hA_h, hA_l, last);
+    layer16<4, 4, 4, 0, true>(p, 0 /*already in flight*/, 2 * NR16_NB_MID, hB_h, hB_l, hA_h, hA_l, last);
 #pragma unroll 1
     for (int l = 1; l <= 3; ++l) {
-        const int nb = l == 3 ? NR16_NB_L4 : NR16_NB_MID;
-        layer16<4, 1, 0, 8, true>(p, nb, nb, hA_h, hA_l, hB_h, hB_l, last);
+        // 128-wide tiles have only 8 k-steps: two tiles per slab halve the barriers per MFMA
+        const int nb = l == 3 ? NR16_NB_L4 : 2 * NR16_NB_MID;
+        layer16<4, 2, 0, 8, true>(p, nb, nb, hA_h, hA_l, hB_h, hB_l, last);
 #pragma unroll
         for (int i = 0; i < 8; ++i) { hA_h[i] = hB_h[i]; hA_l[i] = hB_l[i]; }
     }
-    layer16<4, 1, 4, 8, true>(p, NR16_NB_MID, NR16_NB_MID, hA_h, hA_l, hB_h, hB_l, last);    // skip layer
-    layer16<4, 1, 0, 8, true>(p, NR16_NB_MID, 0, hB_h, hB_l, hA_h, hA_l, last);
+    layer16<4, 1, 4, 8, true>(p, 2 * NR16_NB_MID, 2 * NR16_NB_MID, hA_h, hA_l, hB_h, hB_l, last);    // skip layer
+    layer16<4, 2, 0, 8, true>(p, NR16_NB_MID, 0, hB_h, hB_l, hA_h, hA_l, last);
     h16x8 dh[2], dl[2];
     layer16<1, 1, 0, 8, false>(p, 0, 0, hA_h, hA_l, dh, dl, last);
     const float* ob = reinterpret_cast<const float*>(packed + NR16_BIAS + NR16_BIAS_LDS);

@@ -14,6 +14,9 @@
 
 namespace hnrf {
 
+// 8-byte gather that only promises 4-byte alignment
+struct __attribute__((packed, aligned(4))) f32x2u { float x, y; };
+
 // torch.linspace(0, 1, S)[s] in fp32 (start + step*i below the midpoint,
 // end - step*(S-1-i) above it), then the reference's lerp (network.py:457-458).
 __device__ __forceinline__ float z_at(float nr, float fr, int s, int S) {
@@ -78,14 +81,21 @@ __global__ __launch_bounds__(256) void sample_warp_kernel(
         const bool vx0 = (x0 >= 0) & (x0 < G), vx1 = (x0 + 1 >= 0) & (x0 + 1 < G);
         const bool vy0 = (y0 >= 0) & (y0 < G), vy1 = (y0 + 1 >= 0) & (y0 + 1 < G);
         const bool vz0 = (z0 >= 0) & (z0 < G), vz1 = (z0 + 1 >= 0) & (z0 + 1 < G);
-        const int cx0 = min(max(x0, 0), G - 1), cx1 = min(max(x0 + 1, 0), G - 1);
+        // x-neighbours are adjacent in memory: one 8-byte gather at clamp(x0, 0, G-2) serves both corners
+        // (whichever of the two is out of range is masked below, so only the in-range one has to be right)
+        const int xb = min(max(x0, 0), G - 2);
+        const bool lo_is_a = (x0 == xb), hi_is_b = (x0 == xb);   // x0 == G-1 -> corner 0 is .y; x0 == -1 -> corner 1 is .x
         const int cy0 = min(max(y0, 0), G - 1), cy1 = min(max(y0 + 1, 0), G - 1);
         const int cz0 = min(max(z0, 0), G - 1), cz1 = min(max(z0 + 1, 0), G - 1);
-        const float* vb = vol + (size_t)b * G * GG;
-        const float v000 = vb[cz0 * GG + cy0 * G + cx0], v001 = vb[cz0 * GG + cy0 * G + cx1];
-        const float v010 = vb[cz0 * GG + cy1 * G + cx0], v011 = vb[cz0 * GG + cy1 * G + cx1];
-        const float v100 = vb[cz1 * GG + cy0 * G + cx0], v101 = vb[cz1 * GG + cy0 * G + cx1];
-        const float v110 = vb[cz1 * GG + cy1 * G + cx0], v111 = vb[cz1 * GG + cy1 * G + cx1];
+        const float* vb = vol + (size_t)b * G * GG + xb;
+        const f32x2u p00 = *(const f32x2u*)(vb + cz0 * GG + cy0 * G);
+        const f32x2u p01 = *(const f32x2u*)(vb + cz0 * GG + cy1 * G);
+        const f32x2u p10 = *(const f32x2u*)(vb + cz1 * GG + cy0 * G);
+        const f32x2u p11 = *(const f32x2u*)(vb + cz1 * GG + cy1 * G);
+        const float v000 = lo_is_a ? p00.x : p00.y, v001 = hi_is_b ? p00.y : p00.x;
+        const float v010 = lo_is_a ? p01.x : p01.y, v011 = hi_is_b ? p01.y : p01.x;
+        const float v100 = lo_is_a ? p10.x : p10.y, v101 = hi_is_b ? p10.y : p10.x;
+        const float v110 = lo_is_a ? p11.x : p11.y, v111 = hi_is_b ? p11.y : p11.x;
         float w = 0.f;
         w += (vz0 & vy0 & vx0) ? v000 * (wx0 * wy0 * wz0) : 0.f;
         w += (vz0 & vy0 & vx1) ? v001 * (wx1 * wy0 * wz0) : 0.f;
