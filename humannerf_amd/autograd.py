@@ -2,8 +2,8 @@
 
 ``RenderRays`` is one differentiable op = Network._render_rays (network.py:474-602) for one
 ray chunk.  Forward: K1, K2/K3 in their activation-saving variants, K4.  Backward: K4',
-library GEMMs on the saved activation matrices for the two MLPs (dW = dZ^T X, dX = dZ W,
-relu' from the saved post-activation), PE', K1'.  Gradients are produced for the motion
+for the two MLPs hnrf_mlp_dw (dW = dZ^T X and db, one workgroup per CU holding the whole
+output) + library GEMMs for dX = dZ W (relu' from the saved post-activation), PE', K1'.  Gradients are produced for the motion
 bases, the weight volume and all MLP parameters -- exactly the tensors through which the
 reference's four parameter groups receive gradient (last row).
 """
@@ -23,32 +23,34 @@ def _mlp_backward(dY, acts, weights, first_inputs, skip_layer, skip_order):
     gW, gb = [None] * (n_hidden + 1), [None] * (n_hidden + 1)
     pe = first_inputs
     npe = pe.shape[1]
-    gW[n_hidden] = dY.t() @ acts[n_hidden - 1]
+    gW[n_hidden] = dY.t() @ acts[n_hidden - 1]                         # 3- / 4-row head: library GEMM
     gb[n_hidden] = dY.sum(0)
     dH = dY @ weights[n_hidden]
     dPE = None
     for l in range(n_hidden - 1, -1, -1):
         dZ = torch.ops.aten.threshold_backward(dH, acts[l], 0.0)      # relu'
-        gb[l] = dZ.sum(0)
         W = weights[l]
         if l == 0:
-            gW[l] = dZ.t() @ pe
+            gW[l], gb[l] = ops.mlp_dw(dZ, pe)
             d = dZ @ W[:, -npe:] if W.shape[1] != npe else dZ @ W
             dPE = d if dPE is None else dPE + d
         elif l == skip_layer:
             X = acts[l - 1]
+            gW[l] = torch.empty_like(W)
             if skip_order == 'pe_first':
-                gW[l] = torch.cat([dZ.t() @ pe, dZ.t() @ X], dim=1)
+                ops.mlp_dw(dZ, pe, gW[l][:, :npe], want_db=False)
+                _, gb[l] = ops.mlp_dw(dZ, X, gW[l][:, npe:])
                 dX = dZ @ W
                 dPE = dX[:, :npe].contiguous() if dPE is None else dPE + dX[:, :npe]
                 dH = dX[:, npe:].contiguous()
             else:
-                gW[l] = torch.cat([dZ.t() @ X, dZ.t() @ pe], dim=1)
+                _, gb[l] = ops.mlp_dw(dZ, X, gW[l][:, :-npe])
+                ops.mlp_dw(dZ, pe, gW[l][:, -npe:], want_db=False)
                 dX = dZ @ W
                 dPE = dX[:, -npe:].contiguous() if dPE is None else dPE + dX[:, -npe:]
                 dH = dX[:, :-npe].contiguous()
         else:
-            gW[l] = dZ.t() @ acts[l - 1]
+            gW[l], gb[l] = ops.mlp_dw(dZ, acts[l - 1])
             dH = dZ @ W
     return gW, gb, dPE
 

@@ -240,6 +240,34 @@ def pe_bwd(x, g, hann_w, n_bands, include_input, out=None):
     return out
 
 
+_dw_ws = {}
+
+
+def mlp_dw(dZ, X, dW_out=None, want_db=True):
+    """dW = dZ^T X (and db = column sums of dZ) for one nn.Linear: dZ [P, n_out], X [P, n_in], row-major views
+    whose last dimension is contiguous.  ``dW_out``: optional [n_out, >= n_in] view to write into (row stride kept)."""
+    lib = _lib.load()
+    assert dZ.dtype == torch.float32 and X.dtype == torch.float32 and dZ.is_cuda and X.is_cuda
+    assert dZ.dim() == 2 and X.dim() == 2 and dZ.stride(1) == 1 and X.stride(1) == 1 and dZ.shape[0] == X.shape[0]
+    P, n_out = dZ.shape
+    n_in = X.shape[1]
+    if dW_out is None:
+        dW_out = torch.empty(n_out, n_in, device=dZ.device)
+    assert dW_out.stride(1) == 1 and dW_out.shape[0] == n_out and dW_out.shape[1] == n_in
+    db = torch.empty(n_out, device=dZ.device) if want_db else None
+    need = lib.hnrf_mlp_dw_workspace_bytes(P, n_out, n_in)
+    if need == 0:
+        raise _lib.HnrfError('hnrf_mlp_dw: shape (%d, %d, %d) not built' % (P, n_out, n_in))
+    key = dZ.device.index
+    ws = _dw_ws.get(key)
+    if ws is None or ws.numel() < need:
+        ws = _dw_ws[key] = torch.empty(need, dtype=torch.uint8, device=dZ.device)
+    _lib.check(lib.hnrf_mlp_dw(dZ.data_ptr(), dZ.stride(0), X.data_ptr(), X.stride(0), P, n_out, n_in,
+                               dW_out.data_ptr(), dW_out.stride(0), _ptr(db), ws.data_ptr(), ws.numel(), _stream()),
+               'hnrf_mlp_dw')
+    return dW_out, db
+
+
 def sample_warp_bwd(rays_o, rays_d, z_vals, motion_Rs, motion_Ts, vol, bbox_min, bbox_scale, x_skel, fg_mask,
                     g_x_skel, g_mask):
     """Returns d_vol (same shape as vol; background channel zero), d_Rs (B,3,3), d_Ts (B,3)."""

@@ -187,6 +187,17 @@ int hnrf_sample_warp_bwd(const float* rays_o, const float* rays_d, const float* 
                          int64_t R, int S, int B, int G,
                          float* d_vol, float* d_Rs, float* d_Ts, void* stream);
 
+/* Weight / bias gradient of one nn.Linear inside the two MLPs (autograd of the Linear layers of
+ * canonical_mlps/mlp_rgb_sigma.py and non_rigid_motion_mlps/mlp_offset.py under trainer.py:139-170):
+ *   dW[o][i] = sum_s dZ[s][o] X[s][i]  for o < n_out, i < n_in;   db[o] = sum_s dZ[s][o]  (db may be NULL).
+ *  dZ [P, ldz >= n_out], X [P, ldx >= n_in] row-major fp32; dW written with row stride ldw (so the two
+ *  column blocks of a skip layer's weight are two calls).  Built shapes: n_out 128 | 256;
+ *  n_in 128 | 256 (X 16-byte aligned, ldx % 4 == 0) or n_in <= 64 (any ldx: the PE matrices).
+ *  fp32 MFMA, deterministic (fixed-order slice reduction).  workspace: hnrf_mlp_dw_workspace_bytes. */
+size_t hnrf_mlp_dw_workspace_bytes(int64_t P, int n_out, int n_in);
+int hnrf_mlp_dw(const float* dZ, int64_t ldz, const float* X, int64_t ldx, int64_t P, int n_out, int n_in,
+                float* dW, int64_t ldw, float* db, void* workspace, size_t workspace_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,30 @@
+"""Scratch: dW kernel vs torch, and timing."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from humannerf_amd import ops
+dev = torch.device('cuda:0')
+torch.manual_seed(0)
+def bench(f, n=5):
+    f(); torch.cuda.synchronize(); t = time.perf_counter()
+    for _ in range(n): f()
+    torch.cuda.synchronize(); return (time.perf_counter() - t) / n * 1e3
+for P in (1000, 786432):
+    for n_out, n_in, ldx in ((256, 256, 256), (256, 63, 63), (128, 128, 128), (128, 36, 36), (256, 128, 128), (128, 256, 256)):
+        dZ = torch.randn(P, n_out, device=dev) * (torch.rand(P, n_out, device=dev) > 0.5)
+        X = torch.relu(torch.randn(P, ldx, device=dev))
+        ref_w = (dZ.double().t() @ X.double()); ref_b = dZ.double().sum(0)
+        w, b = ops.mlp_dw(dZ, X)
+        ew = float((w.double() - ref_w).abs().max() / ref_w.abs().max()); eb = float((b.double() - ref_b).abs().max() / ref_b.abs().max())
+        tw = (dZ.t() @ X).double(); et = float((tw - ref_w).abs().max() / ref_w.abs().max())
+        line = f'P={P} {n_out}x{n_in}: rel err dW {ew:.2e} (torch {et:.2e}) db {eb:.2e}'
+        if P > 1000:
+            line += '  hnrf %.3f ms  torch %.3f ms' % (bench(lambda: ops.mlp_dw(dZ, X)), bench(lambda: (dZ.t() @ X, dZ.sum(0))))
+        print(line)
+# skip-layer style: write into a column block of a wider matrix
+P = 5000
+dZ = torch.randn(P, 256, device=dev); pe = torch.randn(P, 63, device=dev); hcat = torch.randn(P, 256, device=dev)
+full = torch.zeros(256, 319, device=dev)
+ops.mlp_dw(dZ, pe, full[:, :63], want_db=False); ops.mlp_dw(dZ, hcat, full[:, 63:])
+ref = dZ.t() @ torch.cat([pe, hcat], 1)
+print('skip block err', float((full - ref).abs().max() / ref.abs().max()))
