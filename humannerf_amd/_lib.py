@@ -27,13 +27,19 @@ SIGNATURES = {
     'hnrf_compact_samples': (_int, [_vp, ctypes.c_float, _i64, _vp, _vp, _vp]),
     'hnrf_canonical_fwd_sparse': (_int, [_vp, _vp, _int, _i64, _vp, _vp, _vp, _vp]),
     'hnrf_nonrigid_fwd_sparse': (_int, [_vp, _vp, _vp, _int, _i64, _vp, _vp, _vp, _vp, _vp]),
-    'hnrf_canonical_fwd_train': (_int, [_vp, _vp, _int, _i64, _vp, _vp, _vp, _vp]),
-    'hnrf_nonrigid_fwd_train': (_int, [_vp, _vp, _vp, _int, _i64, _vp, _vp, _vp, _vp, _vp]),
+    'hnrf_canonical_fwd_train': (_int, [_vp, _vp, _int, _i64, _vp, _vp, _vp, _vp, _vp]),
+    'hnrf_nonrigid_fwd_train': (_int, [_vp, _vp, _vp, _int, _i64, _vp, _vp, _vp, _vp, _vp, _vp]),
     'hnrf_composite_bwd': (_int, [_vp] * 8 + [_i64, _int, _vp, _vp, _vp]),
     'hnrf_pe_bwd': (_int, [_vp, _vp, _vp, _i64, _int, _int, _int, _vp, _vp]),
     'hnrf_sample_warp_bwd': (_int, [_vp] * 12 + [_i64, _int, _int, _int, _vp, _vp, _vp, _vp]),
     'hnrf_mlp_dw_workspace_bytes': (_sz, [_i64, _int, _int]),
     'hnrf_mlp_dw': (_int, [_vp, _i64, _vp, _i64, _i64, _int, _int, _vp, _i64, _vp, _vp, _sz, _vp]),
+    'hnrf_canonical_bwd_packed_bytes': (_sz, []),
+    'hnrf_nonrigid_bwd_packed_bytes': (_sz, []),
+    'hnrf_canonical_bwd_pack': (_int, [_vp, _vp, _vp]),
+    'hnrf_nonrigid_bwd_pack': (_int, [_vp, _vp, _vp]),
+    'hnrf_canonical_bwd': (_int, [_vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp]),
+    'hnrf_nonrigid_bwd': (_int, [_vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp]),
     'hnrf_render_workspace_bytes': (_sz, [_i64, _int]),
     'hnrf_render_rays_fwd': (_int, [_vp] * 14 + [_int, ctypes.c_float, _i64, _int, _int, _int, _vp, _sz, _vp, _vp, _vp, _vp, _vp, _vp]),
 }

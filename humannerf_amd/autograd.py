@@ -2,8 +2,9 @@
 
 ``RenderRays`` is one differentiable op = Network._render_rays (network.py:474-602) for one
 ray chunk.  Forward: K1, K2/K3 in their activation-saving variants, K4.  Backward: K4',
-for the two MLPs hnrf_mlp_dw (dW = dZ^T X and db, one workgroup per CU holding the whole
-output) + library GEMMs for dX = dZ W (relu' from the saved post-activation), PE', K1'.  Gradients are produced for the motion
+for the two MLPs the register-resident dX chain (hnrf_*_bwd: relu' from the saved
+post-activations, PE' fused) and hnrf_mlp_dw (dW = dZ^T X and db, one workgroup per CU
+holding the whole output), K1'.  No library GEMM is left on the per-sample path.  Gradients are produced for the motion
 bases, the weight volume and all MLP parameters -- exactly the tensors through which the
 reference's four parameter groups receive gradient (last row).
 """
@@ -12,47 +13,25 @@ import torch
 from . import ops
 
 
-def _mlp_backward(dY, acts, weights, first_inputs, skip_layer, skip_order):
-    """Backward of a ReLU MLP given the saved post-ReLU activations.
-
-    dY: gradient at the (linear) head output.  acts[l] = output of hidden layer l.
-    first_inputs: PE matrix feeding layer 0 (and the skip layer).  skip_order: 'pe_first' |
-    'h_first' (column order of the skip layer's weight).  Returns (grad weights, grad biases,
-    dPE accumulated over layer 0 and the skip layer)."""
+def _weight_grads(dZ, acts, pe, dY, weights, skip_layer, skip_order):
+    """dW / db of every layer from the chain kernel's dZ [L][P][W], the saved activations and PE matrix.
+    dY: gradient at the (3- / 4-wide) head output."""
     n_hidden = acts.shape[0]
-    gW, gb = [None] * (n_hidden + 1), [None] * (n_hidden + 1)
-    pe = first_inputs
     npe = pe.shape[1]
-    gW[n_hidden] = dY.t() @ acts[n_hidden - 1]                         # 3- / 4-row head: library GEMM
-    gb[n_hidden] = dY.sum(0)
-    dH = dY @ weights[n_hidden]
-    dPE = None
-    for l in range(n_hidden - 1, -1, -1):
-        dZ = torch.ops.aten.threshold_backward(dH, acts[l], 0.0)      # relu'
-        W = weights[l]
+    gW, gb = [None] * (n_hidden + 1), [None] * (n_hidden + 1)
+    gW[n_hidden], gb[n_hidden] = ops.mlp_dw(dY, acts[n_hidden - 1])
+    for l in range(n_hidden):
         if l == 0:
-            gW[l], gb[l] = ops.mlp_dw(dZ, pe)
-            d = dZ @ W[:, -npe:] if W.shape[1] != npe else dZ @ W
-            dPE = d if dPE is None else dPE + d
+            gW[l], gb[l] = ops.mlp_dw(dZ[l], pe)
         elif l == skip_layer:
-            X = acts[l - 1]
-            gW[l] = torch.empty_like(W)
-            if skip_order == 'pe_first':
-                ops.mlp_dw(dZ, pe, gW[l][:, :npe], want_db=False)
-                _, gb[l] = ops.mlp_dw(dZ, X, gW[l][:, npe:])
-                dX = dZ @ W
-                dPE = dX[:, :npe].contiguous() if dPE is None else dPE + dX[:, :npe]
-                dH = dX[:, npe:].contiguous()
-            else:
-                _, gb[l] = ops.mlp_dw(dZ, X, gW[l][:, :-npe])
-                ops.mlp_dw(dZ, pe, gW[l][:, -npe:], want_db=False)
-                dX = dZ @ W
-                dPE = dX[:, -npe:].contiguous() if dPE is None else dPE + dX[:, -npe:]
-                dH = dX[:, :-npe].contiguous()
+            gW[l] = torch.empty_like(weights[l])
+            pe_cols = gW[l][:, :npe] if skip_order == 'pe_first' else gW[l][:, -npe:]
+            h_cols = gW[l][:, npe:] if skip_order == 'pe_first' else gW[l][:, :-npe]
+            ops.mlp_dw(dZ[l], pe, pe_cols, want_db=False)
+            _, gb[l] = ops.mlp_dw(dZ[l], acts[l - 1], h_cols)
         else:
-            gW[l], gb[l] = ops.mlp_dw(dZ, acts[l - 1])
-            dH = dZ @ W
-    return gW, gb, dPE
+            gW[l], gb[l] = ops.mlp_dw(dZ[l], acts[l - 1])
+    return gW, gb
 
 
 class RenderRays(torch.autograd.Function):
@@ -68,35 +47,37 @@ class RenderRays(torch.autograd.Function):
                                              bbox_scale, n_samples, want_bmw=False)
         if use_nonrigid:
             nr_packed = ops.nonrigid_pack(nr_w, nr_b, cond, 'f32')
-            xyz, _, pe_n, acts_n = ops.nonrigid_train(x_skel, hann_w, nr_packed)
+            xyz, _, pe_n, acts_n, bits_n = ops.nonrigid_train(x_skel, hann_w, nr_packed)
         else:
-            xyz, pe_n, acts_n = x_skel, None, None
+            xyz, pe_n, acts_n, bits_n = x_skel, None, None, None
         cn_packed = ops.canonical_pack(cn_w, cn_b, 'f32')
-        raw, pe_c, acts_c = ops.canonical_train(xyz, cn_packed)
+        raw, pe_c, acts_c, bits_c = ops.canonical_train(xyz, cn_packed)
         out = ops.composite(raw, mask, z, rays_d, None, bg, diagnostics=False)
         ctx.use_nonrigid = use_nonrigid
         ctx.save_for_backward(rays_o, rays_d, z, x_skel, mask, xyz, raw, pe_c, acts_c, pe_n, acts_n, motion_Rs,
-                              motion_Ts, vol, bbox_min, bbox_scale, hann_w, cond, bg, *nr_w, *cn_w)
+                              motion_Ts, vol, bbox_min, bbox_scale, hann_w, cond, bg, bits_c, bits_n, *nr_w, *cn_w)
         return out['rgb'], out['alpha'], out['depth']
 
     @staticmethod
     def backward(ctx, g_rgb, g_alpha, g_depth):
         (rays_o, rays_d, z, x_skel, mask, xyz, raw, pe_c, acts_c, pe_n, acts_n, motion_Rs, motion_Ts, vol, bbox_min,
-         bbox_scale, hann_w, cond, bg) = ctx.saved_tensors[:19]
-        nr_w = list(ctx.saved_tensors[19:26])
-        cn_w = list(ctx.saved_tensors[26:35])
+         bbox_scale, hann_w, cond, bg, bits_c, bits_n) = ctx.saved_tensors[:21]
+        nr_w = list(ctx.saved_tensors[21:28])
+        cn_w = list(ctx.saved_tensors[28:37])
         P = z.numel()
         c = lambda t: None if t is None else t.contiguous()
         d_raw, d_mask = ops.composite_bwd(raw, mask, z, rays_d, bg, c(g_rgb), c(g_alpha), c(g_depth))
-        # canonical MLP: skip layer 5 takes [PE63 | h]
-        gWc, gbc, dPE = _mlp_backward(d_raw.view(P, 4), acts_c, cn_w, pe_c, skip_layer=5, skip_order='pe_first')
-        d_xyz = ops.pe_bwd(xyz.reshape(P, 3), dPE.contiguous(), None, 10, True)
+        # canonical MLP (skip layer 5 takes [PE63 | h]): dX chain with the PE backward fused, then the weight gradients
+        d_raw = d_raw.view(P, 4)
+        dZc, d_xyz = ops.canonical_bwd(xyz.reshape(P, 3), d_raw, bits_c, cn_w)
+        gWc, gbc = _weight_grads(dZc, acts_c, pe_c, d_raw, cn_w, skip_layer=5, skip_order='pe_first')
+        del dZc
         if ctx.use_nonrigid:
             # xyz = x_skel + offset; layer 0 input [cond69 | PE36], skip layer 4 takes [h | PE36]
-            gWn, gbn, dPEn = _mlp_backward(d_xyz, acts_n, nr_w, pe_n, skip_layer=4, skip_order='h_first')
+            dZn, d_x_skel = ops.nonrigid_bwd(x_skel.reshape(P, 3), hann_w, d_xyz, bits_n, nr_w)
+            gWn, gbn = _weight_grads(dZn, acts_n, pe_n, d_xyz, nr_w, skip_layer=4, skip_order='h_first')
             # condition-code columns of layer 0: the same vector for every sample
             gWn[0] = torch.cat([gbn[0][:, None] * cond.reshape(1, -1), gWn[0]], dim=1)
-            d_x_skel = ops.pe_bwd(x_skel.reshape(P, 3), dPEn.contiguous(), hann_w, 6, False, out=d_xyz.clone())
         else:
             gWn, gbn = [None] * 7, [None] * 7
             d_x_skel = d_xyz

@@ -28,22 +28,11 @@
 // (99.4 % of the issued MACs are algorithmic; the rest is K/N padding).
 #include "hnrf_common.h"
 #include "hnrf_sincos.h"
+#include "hnrf_mlp_layout.h"
 
 namespace hnrf {
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-
-constexpr int PF = 4;   // weight prefetch distance in groups (4 K-steps = 256 MFMA cycles each)
-
-// Feature of the previous layer's output contracted at K-step j on lane half h.
-__host__ __device__ inline int hid_feat(int j, int h) {
-    const int t = j >> 4, r = j & 15;
-    return 32 * t + 8 * (r >> 2) + 4 * h + (r & 3);
-}
-
 // ------------------------------------------------------------------ packing
-enum { PE_NONE = 0, PE_CANONICAL = 1, PE_NONRIGID = 2 };
-
 struct PackLayer {
     const float* W;      // nn.Linear weight (n_out, n_in)
     const float* b;      // (n_out)
@@ -57,21 +46,6 @@ struct PackLayer {
     int64_t w_off;       // float offset of this layer in the packed image
     int64_t b_off;       // float offset of this layer's bias block
 };
-
-// Column of W contracted by PE K-step j on lane half h (-1: zero padding).
-// canonical (embedders/fourier.py): [x(3) | sin(2^k x)(3) cos(2^k x)(3)]_k=0..9
-//   steps 0..29 = (band k, axis): h=0 sin, h=1 cos; step 30 = (x0, x1); 31 = (x2, 0).
-// non-rigid (embedders/hannw_fourier.py): [w_k sin(2^k x)(3) w_k cos(2^k x)(3)]_k=0..5
-//   steps 0..17 = (band k, axis): h=0 sin, h=1 cos; steps 18.. = padding.
-__device__ inline int pe_col(int kind, int j, int h) {
-    if (kind == PE_CANONICAL) {
-        if (j < 30) return 3 + 6 * (j / 3) + 3 * h + (j % 3);
-        if (j == 30) return h;
-        return h == 0 ? 2 : -1;
-    }
-    if (j < 18) return 6 * (j / 3) + 3 * h + (j % 3);
-    return -1;
-}
 
 __global__ void pack_layer_kernel(PackLayer d, const float* __restrict__ cond, float* __restrict__ packed) {
     const int NG = d.NGA + d.NGB;
@@ -141,14 +115,18 @@ constexpr int64_t NR_FLOATS = NR_B_OFF + 6 * 128 + 32;
 // (float4 units, already offset by lane); `ring` holds the next PF groups.
 // `save` (training): this lane's row of the layer's [P, 32 NT] activation matrix, or nullptr;
 // lane half h writes features 32 t + 8 q + 4 h + (0..3) as one float4 per (t, q).
-template <int NT, int NGA, int NGB, bool A_FIRST, bool RELU, int NA, int NB, int NO>
+// `bits` (training): this lane's NT/2 words of the layer's ReLU sign mask, bit 16 (t & 1) + r of word t >> 1
+// = [register r of tile t is positive] -- what the backward chain needs instead of re-reading the activations.
+template <int PH, int NT, int NGA, int NGB, bool A_FIRST, bool RELU, int NA, int NB, int NO>
 __device__ __forceinline__ void mlp_layer(const float4* __restrict__& wptr, float4 (&ring)[PF],
                                           const float* __restrict__ bias, const float (&a)[NA],
                                           const float (&b)[NB], float (&out)[NO], float* save = nullptr,
-                                          int h = 0) {
+                                          int h = 0, uint32_t* bits = nullptr) {
     static_assert(NA >= NGA * 4 && NB >= NGB * 4 && NO >= NT * 16, "operand arrays too small");
-    static_assert((NT * (NGA + NGB)) % PF == 0, "layer must keep the prefetch ring phase");
     constexpr int NG = NGA + NGB;
+    uint32_t bw[(NT + 1) / 2];
+#pragma unroll
+    for (int i = 0; i < (NT + 1) / 2; ++i) bw[i] = 0u;
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
         const float4* bp = reinterpret_cast<const float4*>(bias + t * 32);
@@ -156,7 +134,7 @@ __device__ __forceinline__ void mlp_layer(const float4* __restrict__& wptr, floa
         f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int g = 0; g < NG; ++g) {
-            const int slot = (t * NG + g) % PF;
+            const int slot = (PH + t * NG + g) % PF;   // PH: groups consumed before this layer, mod PF
             const float4 w = ring[slot];
             ring[slot] = wptr[PF * 64];
             wptr += 64;
@@ -172,6 +150,9 @@ __device__ __forceinline__ void mlp_layer(const float4* __restrict__& wptr, floa
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w.y, o1, acc, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w.z, o2, acc, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w.w, o3, acc, 0, 0, 0);
+            // pin the weight load PF groups ahead of its use (at the 256-VGPR limit hipcc otherwise sinks some of
+            // them to the consuming MFMA: load; s_waitcnt vmcnt(0); mfma)
+            __builtin_amdgcn_sched_barrier(0);
         }
         const float bs[16] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w,
                               b2.x, b2.y, b2.z, b2.w, b3.x, b3.y, b3.z, b3.w};
@@ -186,7 +167,15 @@ __device__ __forceinline__ void mlp_layer(const float4* __restrict__& wptr, floa
                 *reinterpret_cast<float4*>(save + 32 * t + 8 * q + 4 * h) =
                     make_float4(out[t * 16 + 4 * q], out[t * 16 + 4 * q + 1], out[t * 16 + 4 * q + 2],
                                 out[t * 16 + 4 * q + 3]);
+            uint32_t m = 0u;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) m |= (out[t * 16 + r] > 0.f ? 1u : 0u) << r;
+            bw[t >> 1] |= m << (16 * (t & 1));
         }
+    }
+    if (save != nullptr && bits != nullptr) {
+#pragma unroll
+        for (int i = 0; i < (NT + 1) / 2; ++i) bits[i] = bw[i];
     }
 }
 
@@ -202,7 +191,8 @@ template <bool SAVE>
 __global__ __launch_bounds__(256) void canonical_f32_kernel(const float* __restrict__ xyz,
                                                             const float* __restrict__ packed, int64_t P,
                                                             float4* __restrict__ raw, float* __restrict__ pe_out,
-                                                            float* __restrict__ acts, const int* __restrict__ idx,
+                                                            float* __restrict__ acts, uint32_t* __restrict__ relu_bits,
+                                                            const int* __restrict__ idx,
                                                             const int* __restrict__ count) {
     const int lane = threadIdx.x & 63;
     const int h = lane >> 5;
@@ -230,15 +220,17 @@ __global__ __launch_bounds__(256) void canonical_f32_kernel(const float* __restr
     pe[30] = h ? x[1] : x[0];
     pe[31] = h ? 0.f : x[2];
     float* save = nullptr;                       // this lane's activation row (advances one layer per step)
+    uint32_t* bits = nullptr;                    // this lane's 4 words of the sign mask [8][P][2][4]
     if (SAVE && slot < P) {
         save = acts + sample * 256;
+        bits = relu_bits + sample * 8 + h * 4;
 #pragma unroll
         for (int j = 0; j < 32; ++j) {
             const int col = pe_col(PE_CANONICAL, j, h);
             if (col >= 0) pe_out[sample * 63 + col] = pe[j];
         }
     }
-    const int64_t act_stride = P * 256;
+    const int64_t act_stride = P * 256, bit_stride = P * 8;
 
     const float4* wptr = reinterpret_cast<const float4*>(packed) + lane;
     const float* bias = packed + CNL_B_OFF + h * 16;
@@ -247,32 +239,35 @@ __global__ __launch_bounds__(256) void canonical_f32_kernel(const float* __restr
 
     float hA[128], hB[128];
     const float none[1] = {0.f};
-    mlp_layer<8, 8, 0, true, true>(wptr, ring, bias, pe, none, hA, save, h);
+    // ring phase (groups consumed so far, mod PF) entering layers 1..5 and 6..8; 256-group layers keep it
+    constexpr int C_PH1 = (8 * 8) % PF, C_PH6 = (8 * 8 + 8 * 40) % PF;
+    static_assert((8 * 32) % PF == 0, "looped layers must keep the ring phase");
+    mlp_layer<0, 8, 8, 0, true, true>(wptr, ring, bias, pe, none, hA, save, h, bits);
     bias += 256;
-    if (save) save += act_stride;
+    if (save) { save += act_stride; bits += bit_stride; }
 #pragma unroll 1
     for (int l = 1; l <= 4; ++l) {
-        mlp_layer<8, 0, 32, true, true>(wptr, ring, bias, none, hA, hB, save, h);
+        mlp_layer<C_PH1, 8, 0, 32, true, true>(wptr, ring, bias, none, hA, hB, save, h, bits);
         bias += 256;
-        if (save) save += act_stride;
+        if (save) { save += act_stride; bits += bit_stride; }
 #pragma unroll
         for (int i = 0; i < 128; ++i) hA[i] = hB[i];
     }
-    mlp_layer<8, 8, 32, true, true>(wptr, ring, bias, pe, hA, hB, save, h);   // skip: [PE | h]
+    mlp_layer<C_PH1, 8, 8, 32, true, true>(wptr, ring, bias, pe, hA, hB, save, h, bits);   // skip: [PE | h]
     bias += 256;
-    if (save) save += act_stride;
+    if (save) { save += act_stride; bits += bit_stride; }
 #pragma unroll
     for (int i = 0; i < 128; ++i) hA[i] = hB[i];
 #pragma unroll 1
     for (int l = 6; l <= 7; ++l) {
-        mlp_layer<8, 0, 32, true, true>(wptr, ring, bias, none, hA, hB, save, h);
+        mlp_layer<C_PH6, 8, 0, 32, true, true>(wptr, ring, bias, none, hA, hB, save, h, bits);
         bias += 256;
-        if (save) save += act_stride;
+        if (save) { save += act_stride; bits += bit_stride; }
 #pragma unroll
         for (int i = 0; i < 128; ++i) hA[i] = hB[i];
     }
     float o[16];
-    mlp_layer<1, 0, 32, true, false>(wptr, ring, bias, none, hA, o);
+    mlp_layer<C_PH6, 1, 0, 32, true, false>(wptr, ring, bias, none, hA, o);
     // rows 0..3 of the head tile live in registers 0..3 of the lower lane half
     if (h == 0 && slot < P) raw[sample] = make_float4(o[0], o[1], o[2], o[3]);
 }
@@ -284,6 +279,7 @@ __global__ __launch_bounds__(256) void nonrigid_f32_kernel(const float* __restri
                                                            const float* __restrict__ packed, int64_t P,
                                                            float* __restrict__ xyz, float* __restrict__ offsets,
                                                            float* __restrict__ pe_out, float* __restrict__ acts,
+                                                           uint32_t* __restrict__ relu_bits,
                                                            const int* __restrict__ idx, const int* __restrict__ count) {
     const int lane = threadIdx.x & 63;
     const int h = lane >> 5;
@@ -310,12 +306,14 @@ __global__ __launch_bounds__(256) void nonrigid_f32_kernel(const float* __restri
     pe[18] = 0.f;
     pe[19] = 0.f;
     float* save = nullptr;
+    uint32_t* bits = nullptr;                    // sign mask [6][P][2][2]
     if (SAVE && slot < P) {
         save = acts + sample * 128;
+        bits = relu_bits + sample * 4 + h * 2;
 #pragma unroll
         for (int j = 0; j < 18; ++j) pe_out[sample * 36 + pe_col(PE_NONRIGID, j, h)] = pe[j];
     }
-    const int64_t act_stride = P * 128;
+    const int64_t act_stride = P * 128, bit_stride = P * 4;
 
     const float4* wptr = reinterpret_cast<const float4*>(packed) + lane;
     const float* bias = packed + NR_B_OFF + h * 16;
@@ -324,24 +322,26 @@ __global__ __launch_bounds__(256) void nonrigid_f32_kernel(const float* __restri
 
     float hA[64], hB[64];
     const float none[1] = {0.f};
-    mlp_layer<4, 5, 0, true, true>(wptr, ring, bias, pe, none, hA, save, h);
+    constexpr int N_PH1 = (4 * 5) % PF, N_PH5 = (4 * 5 + 4 * 21) % PF;
+    static_assert((4 * 16) % PF == 0, "looped layers must keep the ring phase");
+    mlp_layer<0, 4, 5, 0, true, true>(wptr, ring, bias, pe, none, hA, save, h, bits);
     bias += 128;
-    if (save) save += act_stride;
+    if (save) { save += act_stride; bits += bit_stride; }
 #pragma unroll 1
     for (int l = 1; l <= 3; ++l) {
-        mlp_layer<4, 0, 16, true, true>(wptr, ring, bias, none, hA, hB, save, h);
+        mlp_layer<N_PH1, 4, 0, 16, true, true>(wptr, ring, bias, none, hA, hB, save, h, bits);
         bias += 128;
-        if (save) save += act_stride;
+        if (save) { save += act_stride; bits += bit_stride; }
 #pragma unroll
         for (int i = 0; i < 64; ++i) hA[i] = hB[i];
     }
-    mlp_layer<4, 5, 16, false, true>(wptr, ring, bias, pe, hA, hB, save, h);   // skip: [h | PE]
+    mlp_layer<N_PH1, 4, 5, 16, false, true>(wptr, ring, bias, pe, hA, hB, save, h, bits);   // skip: [h | PE]
     bias += 128;
-    if (save) save += act_stride;
-    mlp_layer<4, 0, 16, true, true>(wptr, ring, bias, none, hB, hA, save, h);
+    if (save) { save += act_stride; bits += bit_stride; }
+    mlp_layer<N_PH5, 4, 0, 16, true, true>(wptr, ring, bias, none, hB, hA, save, h, bits);
     bias += 128;
     float o[16];
-    mlp_layer<1, 0, 16, true, false>(wptr, ring, bias, none, hA, o);
+    mlp_layer<N_PH5, 1, 0, 16, true, false>(wptr, ring, bias, none, hA, o);
     if (h == 0 && slot < P) {
         xyz[sample * 3 + 0] = x[0] + o[0];
         xyz[sample * 3 + 1] = x[1] + o[1];
@@ -462,13 +462,14 @@ extern "C" int hnrf_canonical_fwd_sparse(const float* xyz, const void* packed, i
     if (P == 0) return HNRF_OK;
     if (mode == HNRF_MLP_F16X3) return canonical16_fwd(xyz, packed, P, raw, idx, count, (hipStream_t)stream);
     hipLaunchKernelGGL(canonical_f32_kernel<false>, dim3((unsigned)((P + 127) / 128)), dim3(256), 0,
-                       (hipStream_t)stream, xyz, (const float*)packed, P, (float4*)raw, nullptr, nullptr, idx, count);
+                       (hipStream_t)stream, xyz, (const float*)packed, P, (float4*)raw, nullptr, nullptr, nullptr, idx, count);
     return check_launch("hnrf_canonical_fwd");
 }
 
 extern "C" int hnrf_canonical_fwd_train(const float* xyz, const void* packed, int mode, int64_t P, float* raw,
-                                        float* pe_out, float* acts, void* stream) {
-    HNRF_REQUIRE(xyz && packed && raw && pe_out && acts, HNRF_E_ARG, "hnrf_canonical_fwd_train: null pointer");
+                                        float* pe_out, float* acts, uint32_t* relu_bits, void* stream) {
+    HNRF_REQUIRE(xyz && packed && raw && pe_out && acts && relu_bits, HNRF_E_ARG,
+                 "hnrf_canonical_fwd_train: null pointer");
     HNRF_REQUIRE(mode == HNRF_MLP_F32, HNRF_E_UNSUPPORTED,
                  "hnrf_canonical_fwd_train: only HNRF_MLP_F32 saves activations (mode %d)", mode);
     HNRF_REQUIRE(P >= 0 && (P + 127) / 128 < 2147483647LL, HNRF_E_ARG, "hnrf_canonical_fwd_train: bad P");
@@ -476,7 +477,7 @@ extern "C" int hnrf_canonical_fwd_train(const float* xyz, const void* packed, in
                  "hnrf_canonical_fwd_train: packed/raw/acts must be 16-byte aligned");
     if (P == 0) return HNRF_OK;
     hipLaunchKernelGGL(canonical_f32_kernel<true>, dim3((unsigned)((P + 127) / 128)), dim3(256), 0,
-                       (hipStream_t)stream, xyz, (const float*)packed, P, (float4*)raw, pe_out, acts, nullptr, nullptr);
+                       (hipStream_t)stream, xyz, (const float*)packed, P, (float4*)raw, pe_out, acts, relu_bits, nullptr, nullptr);
     return check_launch("hnrf_canonical_fwd_train");
 }
 
@@ -500,14 +501,14 @@ extern "C" int hnrf_nonrigid_fwd_sparse(const float* x_skel, const float* hann_w
     if (mode == HNRF_MLP_F16X3)
         return nonrigid16_fwd(x_skel, hann_w, packed, P, xyz, offsets, idx, count, (hipStream_t)stream);
     hipLaunchKernelGGL(nonrigid_f32_kernel<false>, dim3((unsigned)((P + 127) / 128)), dim3(256), 0,
-                       (hipStream_t)stream, x_skel, hann_w, (const float*)packed, P, xyz, offsets, nullptr, nullptr, idx, count);
+                       (hipStream_t)stream, x_skel, hann_w, (const float*)packed, P, xyz, offsets, nullptr, nullptr, nullptr, idx, count);
     return check_launch("hnrf_nonrigid_fwd");
 }
 
 extern "C" int hnrf_nonrigid_fwd_train(const float* x_skel, const float* hann_w, const void* packed, int mode,
                                        int64_t P, float* xyz, float* offsets, float* pe_out, float* acts,
-                                       void* stream) {
-    HNRF_REQUIRE(x_skel && hann_w && packed && xyz && pe_out && acts, HNRF_E_ARG,
+                                       uint32_t* relu_bits, void* stream) {
+    HNRF_REQUIRE(x_skel && hann_w && packed && xyz && pe_out && acts && relu_bits, HNRF_E_ARG,
                  "hnrf_nonrigid_fwd_train: null pointer");
     HNRF_REQUIRE(mode == HNRF_MLP_F32, HNRF_E_UNSUPPORTED,
                  "hnrf_nonrigid_fwd_train: only HNRF_MLP_F32 saves activations (mode %d)", mode);
@@ -516,6 +517,6 @@ extern "C" int hnrf_nonrigid_fwd_train(const float* x_skel, const float* hann_w,
                  "hnrf_nonrigid_fwd_train: packed/acts must be 16-byte aligned");
     if (P == 0) return HNRF_OK;
     hipLaunchKernelGGL(nonrigid_f32_kernel<true>, dim3((unsigned)((P + 127) / 128)), dim3(256), 0,
-                       (hipStream_t)stream, x_skel, hann_w, (const float*)packed, P, xyz, offsets, pe_out, acts, nullptr, nullptr);
+                       (hipStream_t)stream, x_skel, hann_w, (const float*)packed, P, xyz, offsets, pe_out, acts, relu_bits, nullptr, nullptr);
     return check_launch("hnrf_nonrigid_fwd_train");
 }

@@ -1,4 +1,4 @@
-// Backward of the two MLPs: weight gradients.
+// Backward of the two MLPs: weight gradients (hnrf_mlp_dw) and the dX chain (hnrf_*_bwd, below).
 //
 // dW[o][i] = sum_s dZ[s][o] X[s][i]   (nn.Linear autograd; the reference gets it from
 // loss.backward(), core/train/trainers/human_nerf/trainer.py:139-170), db[o] = sum_s dZ[s][o].
@@ -19,10 +19,11 @@
 // Roofline: MFMA-bound for 256x256 (103 GFLOP per 786 k samples; 1.6 GB of HBM reads
 // = 0.25 ms at 6.5 TB/s vs 0.66 ms at the 157 TFLOP/s fp32-MFMA peak).
 #include "hnrf_common.h"
+#include "hnrf_sincos.h"
+#include "hnrf_mlp_layout.h"
 
 namespace hnrf {
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4v __attribute__((ext_vector_type(4)));
 struct __attribute__((packed, aligned(4))) f32x2p { float x, y; };
 
@@ -141,6 +142,44 @@ __global__ __launch_bounds__(256) void mlp_dw_kernel(const float* __restrict__ d
     }
 }
 
+// Head layers (n_out <= 4: sigma/rgb, xyz offset): no matrix work, one pass over X.  Thread i owns column i of
+// its slice; dY rows arrive through the scalar cache.  Partials in the layout of mlp_dw_kernel (NOW = 4).
+template <int NI>
+__global__ __launch_bounds__(NI) void mlp_dw_head_kernel(const float* __restrict__ dY, int64_t ldy, int n_out,
+                                                          const float* __restrict__ X, int64_t ldx, int64_t P,
+                                                          int64_t per_wg, float* __restrict__ part,
+                                                          float* __restrict__ dbpart) {
+    const int i = threadIdx.x;
+    const int64_t s0 = (int64_t)blockIdx.x * per_wg;
+    const int64_t s1 = s0 + per_wg < P ? s0 + per_wg : P;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f, b = 0.f;
+    const float* xp = X + i;
+    auto step = [&](int64_t s, float x) {
+        const float* g = dY + s * ldy;                        // block-uniform address
+        const float g0 = g[0], g1 = n_out > 1 ? g[1] : 0.f, g2 = n_out > 2 ? g[2] : 0.f, g3 = n_out > 3 ? g[3] : 0.f;
+        a0 = fmaf(g0, x, a0);
+        a1 = fmaf(g1, x, a1);
+        a2 = fmaf(g2, x, a2);
+        a3 = fmaf(g3, x, a3);
+        b += i == 0 ? g0 : (i == 1 ? g1 : (i == 2 ? g2 : g3));
+    };
+    int64_t s = s0;
+    for (; s + 8 <= s1; s += 8) {                             // 8 independent row loads in flight per thread
+        float x[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) x[u] = xp[(s + u) * ldx];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) step(s + u, x[u]);
+    }
+    for (; s < s1; ++s) step(s, xp[s * ldx]);
+    float* out = part + (int64_t)blockIdx.x * 4 * NI;
+    out[i] = a0;
+    out[NI + i] = a1;
+    out[2 * NI + i] = a2;
+    out[3 * NI + i] = a3;
+    if (dbpart != nullptr && i < 4) dbpart[(int64_t)blockIdx.x * 4 + i] = b;
+}
+
 // dW[o][i] = sum over slices; db likewise.  Block = 64 consecutive elements x 4 slice groups (group g takes
 // slices g, g+4, ..), combined through LDS in a fixed order: the result does not depend on scheduling.
 __global__ __launch_bounds__(256) void mlp_dw_reduce_kernel(const float* __restrict__ part,
@@ -186,15 +225,287 @@ struct DwPlan {
 };
 
 static bool dw_plan(int64_t P, int n_out, int n_in, DwPlan& pl) {
-    if (n_out == 256 || n_out == 128) pl.now = n_out; else return false;
-    if (n_in == 256 || n_in == 128) pl.nip = n_in; else if (n_in >= 1 && n_in <= 64) pl.nip = 64; else return false;
+    if (n_out == 256 || n_out == 128) pl.now = n_out; else if (n_out >= 1 && n_out <= 4) pl.now = 4; else return false;
+    if (n_in == 256 || n_in == 128) pl.nip = n_in;
+    else if (n_in >= 1 && n_in <= 64 && n_out > 4) pl.nip = 64;
+    else return false;
     const int64_t unit = 2 * DW_DEPTH;
     int64_t per = (P + DW_SPLIT - 1) / DW_SPLIT;
     per = (per + unit - 1) / unit * unit;
     if (per < 4 * unit) per = 4 * unit;
+    if (pl.now == 4 && per > 512) per = 512;                   // bandwidth-bound head pass: many small slices per CU
     pl.per_wg = per;
     pl.nsplit = (int)((P + per - 1) / per);
     return true;
+}
+
+
+// =========================================================================== dX chain
+// Backward through all layers of one MLP for 32 samples per wave, register-resident like the
+// forward (hnrf_mlp.hip): dH_{l-1}^T [in-features x samples] = W_l^T . dZ_l^T, then
+// dZ_{l-1} = dH_{l-1} * [act_{l-1} > 0] with act read from the matrices the training forward
+// saved.  The MFMA result of one stage is, verbatim, the B operand of the next; the weight image
+// holds W_l^T in A-operand order with the K order of that register layout (hid_feat), and the
+// rows of the two positional-encoding blocks (layer 0 and the skip layer) in the order of the
+// forward's PE K-steps, so that d PE lands on the lane that can recompute sin/cos of its own
+// sample: the PE backward is fused (d_xyz leaves the kernel, d PE never exists in memory).
+// Every dZ_l is written once ([L][P][width], the layout of the saved activations) for
+// hnrf_mlp_dw.  Per sample: 8 KB of activations read + 8 KB of dZ written (canonical).
+
+struct PackBwd {
+    const float* W;        // nn.Linear weight (n_out, n_in) of the forward layer
+    int n_out, n_in;
+    int NT, NG;            // output tiles (rows = forward in-features) / K groups (K = forward out-features)
+    int row_kind;          // PE_NONE: row rho <-> in-feature col0 + rho;  else: rows in PE K-step order
+    int col0;              // first forward in-feature column of this block
+    int head;              // 1: K = the n_out (<= 4) head outputs on lane half 0 of steps 0..3
+    int64_t w_off;         // float offset in the image
+};
+
+__global__ void pack_bwd_kernel(PackBwd d, float* __restrict__ packed) {
+    const int64_t n = (int64_t)d.NT * d.NG * 256;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int e = (int)(i & 3);
+    const int lane = (int)((i >> 2) & 63);
+    const int64_t gg = i >> 8;
+    const int g = (int)(gg % d.NG);
+    const int t = (int)(gg / d.NG);
+    const int h = lane >> 5;
+    const int j = 4 * g + e;                                   // K-step
+    const int o = d.head ? ((h == 0 && j < d.n_out) ? j : -1) : hid_feat(j, h);
+    const int rho = 32 * t + (lane & 31);                      // output row of this stage
+    int col;
+    if (d.row_kind == PE_NONE) {
+        col = d.col0 + rho;
+    } else {
+        // register (tile tt, r) on half hh holds row 32 tt + 8 (r >> 2) + 4 hh + (r & 3): make it PE step 16 tt + r
+        const int tt = rho >> 5, w = rho & 31;
+        const int r = 4 * (w >> 3) + (w & 3), hh = (w >> 2) & 1;
+        const int c = pe_col(d.row_kind, 16 * tt + r, hh);
+        col = c < 0 ? -1 : d.col0 + c;
+    }
+    float v = 0.f;
+    if (o >= 0 && o < d.n_out && col >= 0 && col < d.n_in) v = d.W[(int64_t)o * d.n_in + col];
+    packed[d.w_off + i] = v;
+}
+
+// One backward stage.  b: dZ of the layer above in register layout; out: NT tiles of W^T b.
+// mbits != nullptr: multiply by relu' -- this lane's NT/2 words of the sign mask the training forward wrote
+// (bit 16 (t & 1) + r of word t >> 1 = [register r of tile t was positive]); 16 bytes per lane and layer instead
+// of re-reading the activations: a load that waits on HBM holds back, in the in-order vmcnt queue, the L2-resident
+// weight stream issued behind it, so the stage has exactly one such load, at its start.
+// dz != nullptr: store the masked result (this lane's row of the dZ matrix).
+template <int PH, int NT, int NG, int NB, int NO>
+__device__ __forceinline__ void bwd_stage(const float4* __restrict__& wptr, float4 (&ring)[PF], const float (&b)[NB],
+                                          float (&out)[NO], const uint32_t* __restrict__ mbits,
+                                          float* __restrict__ dz, int h) {
+    static_assert(NB >= NG * 4 && NO >= NT * 16, "operand arrays too small");
+    uint32_t mw[(NT + 1) / 2];
+#pragma unroll
+    for (int i = 0; i < (NT + 1) / 2; ++i) mw[i] = mbits != nullptr ? mbits[i] : 0xffffffffu;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            const int slot = (PH + t * NG + g) % PF;   // PH: groups consumed before this stage, mod PF
+            const float4 w = ring[slot];
+            ring[slot] = wptr[PF * 64];
+            wptr += 64;
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w.x, b[4 * g + 0], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w.y, b[4 * g + 1], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w.z, b[4 * g + 2], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w.w, b[4 * g + 3], acc, 0, 0, 0);
+            // pin the weight load PF groups ahead of its use: at the 256-VGPR limit hipcc otherwise sinks it
+            // to the consuming MFMA (load; s_waitcnt vmcnt(0); mfma) to shorten the live range
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        const uint32_t m = mw[t >> 1] >> (16 * (t & 1));
+#pragma unroll
+        for (int r = 0; r < 16; ++r) out[t * 16 + r] = (m >> r) & 1u ? acc[r] : 0.f;
+        if (dz != nullptr) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                *reinterpret_cast<float4*>(dz + 32 * t + 8 * q + 4 * h) =
+                    make_float4(out[t * 16 + 4 * q], out[t * 16 + 4 * q + 1], out[t * 16 + 4 * q + 2],
+                                out[t * 16 + 4 * q + 3]);
+        }
+    }
+}
+
+// image layouts (floats); every block is [tile][group][lane][4]
+constexpr int64_t CB_HEAD = 0;                                    // W8^T: 8 tiles x 1 group
+constexpr int64_t CB_MID = 8 * 32 * 256;                          // one 256x256 block
+constexpr int64_t CB_L7 = CB_HEAD + 8 * 1 * 256;                  // W7^T, W6^T
+constexpr int64_t CB_L5H = CB_L7 + 2 * CB_MID;                    // W5^T hidden rows
+constexpr int64_t CB_L5P = CB_L5H + CB_MID;                       // W5^T PE rows: 2 tiles x 32 groups
+constexpr int64_t CB_L4 = CB_L5P + 2 * 32 * 256;                  // W4^T .. W1^T
+constexpr int64_t CB_L0P = CB_L4 + 4 * CB_MID;                    // W0^T PE rows
+constexpr int64_t CB_END = CB_L0P + 2 * 32 * 256;
+constexpr int64_t CB_FLOATS = CB_END + PF * 256;                  // prefetch over-run pad
+constexpr int64_t NB_HEAD = 0;                                    // W6^T: 4 tiles x 1 group
+constexpr int64_t NB_MID = 4 * 16 * 256;
+constexpr int64_t NB_L5 = NB_HEAD + 4 * 1 * 256;                  // W5^T
+constexpr int64_t NB_L4H = NB_L5 + NB_MID;                        // W4^T hidden rows
+constexpr int64_t NB_L4P = NB_L4H + NB_MID;                       // W4^T PE rows: 2 tiles x 16 groups
+constexpr int64_t NB_L3 = NB_L4P + 2 * 16 * 256;                  // W3^T .. W1^T
+constexpr int64_t NB_L0P = NB_L3 + 3 * NB_MID;                    // W0^T PE rows
+constexpr int64_t NB_END = NB_L0P + 2 * 16 * 256;
+constexpr int64_t NB_FLOATS = NB_END + PF * 256;
+
+__device__ __forceinline__ void ring_fill_b(const float4* __restrict__ wptr, float4 (&ring)[PF]) {
+#pragma unroll
+    for (int i = 0; i < PF; ++i) ring[i] = wptr[i * 64];
+}
+
+// Canonical MLP.  relu_bits [8][P][2][4] (sign masks of the saved activations), d_raw [P,4]; writes
+// dZ [8][P][256], d_xyz [P,3].
+__global__ __launch_bounds__(256) void canonical_bwd_kernel(const float* __restrict__ xyz,
+                                                            const float4* __restrict__ d_raw,
+                                                            const uint32_t* __restrict__ relu_bits,
+                                                            const float* __restrict__ packed, int64_t P,
+                                                            float* __restrict__ dZ, float* __restrict__ d_xyz) {
+    const int lane = threadIdx.x & 63, h = lane >> 5;
+    const int64_t slot = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 32 + (lane & 31);
+    const int64_t sample = slot < P ? slot : P - 1;            // clamped lanes compute, but never store
+    const bool live = slot < P;
+    const int64_t stride = P * 256;
+
+    const float4 g = d_raw[sample];
+    const float in0[4] = {h ? 0.f : g.x, h ? 0.f : g.y, h ? 0.f : g.z, h ? 0.f : g.w};
+    const float4* wptr = reinterpret_cast<const float4*>(packed) + lane;
+    float4 ring[PF];
+    ring_fill_b(wptr, ring);
+
+    const int64_t bstride = P * 8;
+    const uint32_t* act = relu_bits + 7 * bstride + sample * 8 + h * 4;
+    float* dz = dZ + 7 * stride + sample * 256;
+    float hA[128], hB[128], dpe[32], dpe0[32];
+    constexpr int C_PH = 8 % PF;                               // after the 8-group head every stage is a multiple of 64 groups
+    static_assert(64 % PF == 0, "stages must keep the ring phase");
+    bwd_stage<0, 8, 1>(wptr, ring, in0, hA, act, live ? dz : nullptr, h);                  // dZ7
+#pragma unroll 1
+    for (int l = 7; l >= 6; --l) {                                                      // dZ6, dZ5
+        act -= bstride;
+        dz -= stride;
+        bwd_stage<C_PH, 8, 32>(wptr, ring, hA, hB, act, live ? dz : nullptr, h);
+#pragma unroll
+        for (int i = 0; i < 128; ++i) hA[i] = hB[i];
+    }
+    act -= bstride;
+    dz -= stride;
+    bwd_stage<C_PH, 8, 32>(wptr, ring, hA, hB, act, live ? dz : nullptr, h);                  // skip layer: dZ4 ...
+    bwd_stage<C_PH, 2, 32>(wptr, ring, hA, dpe, nullptr, nullptr, h);                         // ... and its d PE
+#pragma unroll
+    for (int i = 0; i < 128; ++i) hA[i] = hB[i];
+#pragma unroll 1
+    for (int l = 4; l >= 1; --l) {                                                      // dZ3 .. dZ0
+        act -= bstride;
+        dz -= stride;
+        bwd_stage<C_PH, 8, 32>(wptr, ring, hA, hB, act, live ? dz : nullptr, h);
+#pragma unroll
+        for (int i = 0; i < 128; ++i) hA[i] = hB[i];
+    }
+    bwd_stage<C_PH, 2, 32>(wptr, ring, hA, dpe0, nullptr, nullptr, h);                        // layer 0's d PE
+#pragma unroll
+    for (int j = 0; j < 32; ++j) dpe[j] += dpe0[j];
+
+    // PE backward on the lane's own sample (fourier.py): step j = 3 k + axis, half 0 = sin, half 1 = cos
+    const float x[3] = {xyz[sample * 3 + 0], xyz[sample * 3 + 1], xyz[sample * 3 + 2]};
+    float dx[3] = {0.f, 0.f, 0.f};
+    {
+        OctavePhase ph[3] = {OctavePhase(x[0]), OctavePhase(x[1]), OctavePhase(x[2])};
+#pragma unroll
+        for (int j = 0; j < 30; ++j) {
+            float sv, cv;
+            ph[j % 3].next(sv, cv);
+            const float f = (float)(1 << (j / 3));
+            dx[j % 3] += f * (h ? -sv : cv) * dpe[j];
+        }
+    }
+    dx[h ? 1 : 0] += dpe[30];
+    if (h == 0) dx[2] += dpe[31];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) dx[a] += __shfl_xor(dx[a], 32, 64);
+    if (h == 0 && live) {
+        d_xyz[sample * 3 + 0] = dx[0];
+        d_xyz[sample * 3 + 1] = dx[1];
+        d_xyz[sample * 3 + 2] = dx[2];
+    }
+}
+
+// Non-rigid MLP (xyz = x_skel + offset(x_skel)).  relu_bits [6][P][2][2], d_xyz [P,3]; writes dZ [6][P][128] and
+// d_x_skel = d_xyz + (d offset / d x_skel)^T d_xyz.
+__global__ __launch_bounds__(256) void nonrigid_bwd_kernel(const float* __restrict__ x_skel,
+                                                           const float* __restrict__ hann_w,
+                                                           const float* __restrict__ d_xyz,
+                                                           const uint32_t* __restrict__ relu_bits,
+                                                           const float* __restrict__ packed, int64_t P,
+                                                           float* __restrict__ dZ, float* __restrict__ d_x_skel) {
+    const int lane = threadIdx.x & 63, h = lane >> 5;
+    const int64_t slot = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 32 + (lane & 31);
+    const int64_t sample = slot < P ? slot : P - 1;
+    const bool live = slot < P;
+    const int64_t stride = P * 128;
+
+    const float g[3] = {d_xyz[sample * 3 + 0], d_xyz[sample * 3 + 1], d_xyz[sample * 3 + 2]};
+    const float in0[4] = {h ? 0.f : g[0], h ? 0.f : g[1], h ? 0.f : g[2], 0.f};
+    const float4* wptr = reinterpret_cast<const float4*>(packed) + lane;
+    float4 ring[PF];
+    ring_fill_b(wptr, ring);
+
+    const int64_t bstride = P * 4;
+    const uint32_t* act = relu_bits + 5 * bstride + sample * 4 + h * 2;
+    float* dz = dZ + 5 * stride + sample * 128;
+    float hA[64], hB[64], dpe[32], dpe0[32];
+    constexpr int N_PH = 4 % PF;                               // 4-group head, then multiples of 32 groups
+    static_assert(32 % PF == 0, "stages must keep the ring phase");
+    bwd_stage<0, 4, 1>(wptr, ring, in0, hA, act, live ? dz : nullptr, h);                  // dZ5
+    act -= bstride;
+    dz -= stride;
+    bwd_stage<N_PH, 4, 16>(wptr, ring, hA, hB, act, live ? dz : nullptr, h);                  // dZ4 (the skip layer's)
+    act -= bstride;
+    dz -= stride;
+    bwd_stage<N_PH, 4, 16>(wptr, ring, hB, hA, act, live ? dz : nullptr, h);                  // skip [h | PE]: dZ3 ...
+    bwd_stage<N_PH, 2, 16>(wptr, ring, hB, dpe, nullptr, nullptr, h);                         // ... and its d PE
+#pragma unroll 1
+    for (int l = 3; l >= 1; --l) {                                                      // dZ2 .. dZ0
+        act -= bstride;
+        dz -= stride;
+        bwd_stage<N_PH, 4, 16>(wptr, ring, hA, hB, act, live ? dz : nullptr, h);
+#pragma unroll
+        for (int i = 0; i < 64; ++i) hA[i] = hB[i];
+    }
+    bwd_stage<N_PH, 2, 16>(wptr, ring, hA, dpe0, nullptr, nullptr, h);
+#pragma unroll
+    for (int j = 0; j < 18; ++j) dpe[j] += dpe0[j];
+
+    const float x[3] = {x_skel[sample * 3 + 0], x_skel[sample * 3 + 1], x_skel[sample * 3 + 2]};
+    float dx[3] = {0.f, 0.f, 0.f};
+    {
+        OctavePhase ph[3] = {OctavePhase(x[0]), OctavePhase(x[1]), OctavePhase(x[2])};
+#pragma unroll
+        for (int j = 0; j < 18; ++j) {
+            float sv, cv;
+            ph[j % 3].next(sv, cv);
+            const float f = hann_w[j / 3] * (float)(1 << (j / 3));
+            dx[j % 3] += f * (h ? -sv : cv) * dpe[j];
+        }
+    }
+#pragma unroll
+    for (int a = 0; a < 3; ++a) dx[a] += __shfl_xor(dx[a], 32, 64);
+    if (h == 0 && live) {
+        d_x_skel[sample * 3 + 0] = g[0] + dx[0];
+        d_x_skel[sample * 3 + 1] = g[1] + dx[1];
+        d_x_skel[sample * 3 + 2] = g[2] + dx[2];
+    }
+}
+
+static int launch_pack_bwd(const PackBwd& d, float* packed, hipStream_t st) {
+    const int64_t n = (int64_t)d.NT * d.NG * 256;
+    hipLaunchKernelGGL(pack_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d, packed);
+    return check_launch("hnrf pack (backward)");
 }
 
 }  // namespace hnrf
@@ -212,7 +523,7 @@ extern "C" int hnrf_mlp_dw(const float* dZ, int64_t ldz, const float* X, int64_t
     HNRF_REQUIRE(dZ && X && dW && workspace, HNRF_E_ARG, "hnrf_mlp_dw: null pointer");
     DwPlan pl;
     HNRF_REQUIRE(P > 0 && dw_plan(P, n_out, n_in, pl), HNRF_E_UNSUPPORTED,
-                 "hnrf_mlp_dw: shape P=%lld n_out=%d n_in=%d not built (n_out 128|256, n_in 128|256|<=64)",
+                 "hnrf_mlp_dw: shape P=%lld n_out=%d n_in=%d not built (n_out 128|256 with n_in 128|256|<=64; n_out <= 4 with n_in 128|256)",
                  (long long)P, n_out, n_in);
     HNRF_REQUIRE(ldz >= n_out && ldx >= n_in && ldw >= n_in, HNRF_E_ARG, "hnrf_mlp_dw: row stride below width");
     HNRF_REQUIRE(workspace_bytes >= hnrf_mlp_dw_workspace_bytes(P, n_out, n_in), HNRF_E_ARG,
@@ -226,7 +537,14 @@ extern "C" int hnrf_mlp_dw(const float* dZ, int64_t ldz, const float* X, int64_t
 #define HNRF_DW(OT, IB)                                                                                        \
     hipLaunchKernelGGL((mlp_dw_kernel<OT, IB>), dim3(pl.nsplit), dim3(256), 0, st, dZ, ldz, X, ldx, n_in, P, \
                        pl.per_wg, part, db ? dbpart : nullptr)
-    if (n_out == 256) {
+    if (n_out <= 4) {
+        if (n_in == 256)
+            hipLaunchKernelGGL(mlp_dw_head_kernel<256>, dim3(pl.nsplit), dim3(256), 0, st, dZ, ldz, n_out, X, ldx, P,
+                               pl.per_wg, part, db ? dbpart : nullptr);
+        else
+            hipLaunchKernelGGL(mlp_dw_head_kernel<128>, dim3(pl.nsplit), dim3(128), 0, st, dZ, ldz, n_out, X, ldx, P,
+                               pl.per_wg, part, db ? dbpart : nullptr);
+    } else if (n_out == 256) {
         if (n_in == 256) HNRF_DW(2, 2); else if (n_in == 128) HNRF_DW(2, 1); else HNRF_DW(2, 0);
     } else {
         if (n_in == 256) HNRF_DW(1, 2); else if (n_in == 128) HNRF_DW(1, 1); else HNRF_DW(1, 0);
@@ -238,4 +556,79 @@ extern "C" int hnrf_mlp_dw(const float* dZ, int64_t ldz, const float* X, int64_t
     hipLaunchKernelGGL(mlp_dw_reduce_kernel, dim3(nblk), dim3(256), 0, st, part, dbpart, pl.nsplit, pl.now,
                        pl.nip, n_out, n_in, dW, ldw, db);
     return check_launch("hnrf_mlp_dw (reduce)");
+}
+
+extern "C" size_t hnrf_canonical_bwd_packed_bytes(void) { return (size_t)CB_FLOATS * sizeof(float); }
+extern "C" size_t hnrf_nonrigid_bwd_packed_bytes(void) { return (size_t)NB_FLOATS * sizeof(float); }
+
+extern "C" int hnrf_canonical_bwd_pack(const float* const* weights, void* packed, void* stream) {
+    HNRF_REQUIRE(weights && packed, HNRF_E_ARG, "hnrf_canonical_bwd_pack: null pointer");
+    for (int i = 0; i < 9; ++i) HNRF_REQUIRE(weights[i], HNRF_E_ARG, "hnrf_canonical_bwd_pack: null layer %d", i);
+    hipStream_t st = (hipStream_t)stream;
+    float* out = (float*)packed;
+    if (hipMemsetAsync(out + CB_END, 0, PF * 256 * sizeof(float), st) != hipSuccess) {
+        set_error("hnrf_canonical_bwd_pack: memset failed");
+        return HNRF_E_LAUNCH;
+    }
+    int rc;
+    if ((rc = launch_pack_bwd(PackBwd{weights[8], 4, 256, 8, 1, PE_NONE, 0, 1, CB_HEAD}, out, st))) return rc;
+    for (int l = 7; l >= 6; --l)
+        if ((rc = launch_pack_bwd(PackBwd{weights[l], 256, 256, 8, 32, PE_NONE, 0, 0, CB_L7 + (7 - l) * CB_MID}, out, st)))
+            return rc;
+    if ((rc = launch_pack_bwd(PackBwd{weights[5], 256, 319, 8, 32, PE_NONE, 63, 0, CB_L5H}, out, st))) return rc;
+    if ((rc = launch_pack_bwd(PackBwd{weights[5], 256, 319, 2, 32, PE_CANONICAL, 0, 0, CB_L5P}, out, st))) return rc;
+    for (int l = 4; l >= 1; --l)
+        if ((rc = launch_pack_bwd(PackBwd{weights[l], 256, 256, 8, 32, PE_NONE, 0, 0, CB_L4 + (4 - l) * CB_MID}, out, st)))
+            return rc;
+    return launch_pack_bwd(PackBwd{weights[0], 256, 63, 2, 32, PE_CANONICAL, 0, 0, CB_L0P}, out, st);
+}
+
+extern "C" int hnrf_nonrigid_bwd_pack(const float* const* weights, void* packed, void* stream) {
+    HNRF_REQUIRE(weights && packed, HNRF_E_ARG, "hnrf_nonrigid_bwd_pack: null pointer");
+    for (int i = 0; i < 7; ++i) HNRF_REQUIRE(weights[i], HNRF_E_ARG, "hnrf_nonrigid_bwd_pack: null layer %d", i);
+    hipStream_t st = (hipStream_t)stream;
+    float* out = (float*)packed;
+    if (hipMemsetAsync(out + NB_END, 0, PF * 256 * sizeof(float), st) != hipSuccess) {
+        set_error("hnrf_nonrigid_bwd_pack: memset failed");
+        return HNRF_E_LAUNCH;
+    }
+    int rc;
+    if ((rc = launch_pack_bwd(PackBwd{weights[6], 3, 128, 4, 1, PE_NONE, 0, 1, NB_HEAD}, out, st))) return rc;
+    if ((rc = launch_pack_bwd(PackBwd{weights[5], 128, 128, 4, 16, PE_NONE, 0, 0, NB_L5}, out, st))) return rc;
+    if ((rc = launch_pack_bwd(PackBwd{weights[4], 128, 164, 4, 16, PE_NONE, 0, 0, NB_L4H}, out, st))) return rc;
+    if ((rc = launch_pack_bwd(PackBwd{weights[4], 128, 164, 2, 16, PE_NONRIGID, 128, 0, NB_L4P}, out, st))) return rc;
+    for (int l = 3; l >= 1; --l)
+        if ((rc = launch_pack_bwd(PackBwd{weights[l], 128, 128, 4, 16, PE_NONE, 0, 0, NB_L3 + (3 - l) * NB_MID}, out, st)))
+            return rc;
+    return launch_pack_bwd(PackBwd{weights[0], 128, 105, 2, 16, PE_NONRIGID, 69, 0, NB_L0P}, out, st);
+}
+
+extern "C" int hnrf_canonical_bwd(const float* xyz, const float* d_raw, const uint32_t* relu_bits, const void* packed,
+                                  int64_t P, float* dZ, float* d_xyz, void* stream) {
+    HNRF_REQUIRE(xyz && d_raw && relu_bits && packed && dZ && d_xyz, HNRF_E_ARG, "hnrf_canonical_bwd: null pointer");
+    HNRF_REQUIRE(P >= 0, HNRF_E_ARG, "hnrf_canonical_bwd: bad P");
+    HNRF_REQUIRE((((uintptr_t)d_raw | (uintptr_t)relu_bits | (uintptr_t)dZ | (uintptr_t)packed) & 15) == 0, HNRF_E_ARG,
+                 "hnrf_canonical_bwd: d_raw, relu_bits, dZ, packed must be 16-byte aligned");
+    if (P == 0) return HNRF_OK;
+    const int64_t blocks = (P + 127) / 128;
+    HNRF_REQUIRE(blocks < 2147483647LL, HNRF_E_ARG, "hnrf_canonical_bwd: too many samples");
+    hipLaunchKernelGGL(canonical_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, xyz,
+                       (const float4*)d_raw, relu_bits, (const float*)packed, P, dZ, d_xyz);
+    return check_launch("hnrf_canonical_bwd");
+}
+
+extern "C" int hnrf_nonrigid_bwd(const float* x_skel, const float* hann_w, const float* d_xyz,
+                                 const uint32_t* relu_bits, const void* packed, int64_t P, float* dZ,
+                                 float* d_x_skel, void* stream) {
+    HNRF_REQUIRE(x_skel && hann_w && d_xyz && relu_bits && packed && dZ && d_x_skel, HNRF_E_ARG,
+                 "hnrf_nonrigid_bwd: null pointer");
+    HNRF_REQUIRE(P >= 0, HNRF_E_ARG, "hnrf_nonrigid_bwd: bad P");
+    HNRF_REQUIRE((((uintptr_t)relu_bits | (uintptr_t)dZ | (uintptr_t)packed) & 15) == 0, HNRF_E_ARG,
+                 "hnrf_nonrigid_bwd: relu_bits, dZ, packed must be 16-byte aligned");
+    if (P == 0) return HNRF_OK;
+    const int64_t blocks = (P + 127) / 128;
+    HNRF_REQUIRE(blocks < 2147483647LL, HNRF_E_ARG, "hnrf_nonrigid_bwd: too many samples");
+    hipLaunchKernelGGL(nonrigid_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x_skel, hann_w,
+                       d_xyz, relu_bits, (const float*)packed, P, dZ, d_x_skel);
+    return check_launch("hnrf_nonrigid_bwd");
 }

@@ -188,7 +188,8 @@ def render_rays(rays_o, rays_d, near, far, t_rand, motion_Rs, motion_Ts, vol, bb
 
 # ----------------------------------------------------------------------------- training
 def canonical_train(xyz, packed):
-    """hnrf_canonical_fwd_train: raw (...,4), pe (P,63), acts (8,P,256).  fp32 mode only."""
+    """hnrf_canonical_fwd_train: raw (...,4), pe (P,63), acts (8,P,256), relu sign masks (8,P,8) int32.
+    fp32 mode only."""
     lib = _lib.load()
     _chk(xyz, packed)
     P = xyz.numel() // 3
@@ -196,13 +197,14 @@ def canonical_train(xyz, packed):
     raw = torch.empty(*xyz.shape[:-1], 4, device=dev)
     pe = torch.empty(P, 63, device=dev)
     acts = torch.empty(8, P, 256, device=dev)
+    bits = torch.empty(8, P, 8, dtype=torch.int32, device=dev)
     _lib.check(lib.hnrf_canonical_fwd_train(_ptr(xyz), _ptr(packed), MLP_MODES['f32'], P, _ptr(raw), _ptr(pe),
-                                            _ptr(acts), _stream()), 'hnrf_canonical_fwd_train')
-    return raw, pe, acts
+                                            _ptr(acts), bits.data_ptr(), _stream()), 'hnrf_canonical_fwd_train')
+    return raw, pe, acts, bits
 
 
 def nonrigid_train(x_skel, hann_w, packed):
-    """hnrf_nonrigid_fwd_train: xyz, offsets, pe (P,36), acts (6,P,128)."""
+    """hnrf_nonrigid_fwd_train: xyz, offsets, pe (P,36), acts (6,P,128), relu sign masks (6,P,4) int32."""
     lib = _lib.load()
     _chk(x_skel, hann_w, packed)
     P = x_skel.numel() // 3
@@ -210,9 +212,11 @@ def nonrigid_train(x_skel, hann_w, packed):
     xyz, offsets = torch.empty_like(x_skel), torch.empty_like(x_skel)
     pe = torch.empty(P, 36, device=dev)
     acts = torch.empty(6, P, 128, device=dev)
+    bits = torch.empty(6, P, 4, dtype=torch.int32, device=dev)
     _lib.check(lib.hnrf_nonrigid_fwd_train(_ptr(x_skel), _ptr(hann_w), _ptr(packed), MLP_MODES['f32'], P, _ptr(xyz),
-                                           _ptr(offsets), _ptr(pe), _ptr(acts), _stream()), 'hnrf_nonrigid_fwd_train')
-    return xyz, offsets, pe, acts
+                                           _ptr(offsets), _ptr(pe), _ptr(acts), bits.data_ptr(), _stream()),
+               'hnrf_nonrigid_fwd_train')
+    return xyz, offsets, pe, acts, bits
 
 
 def composite_bwd(raw, fg_mask, z_vals, rays_d, bgcolor, g_rgb, g_alpha=None, g_depth=None):
@@ -238,6 +242,38 @@ def pe_bwd(x, g, hann_w, n_bands, include_input, out=None):
     _lib.check(lib.hnrf_pe_bwd(_ptr(x), _ptr(g), _ptr(hann_w), P, n_bands, int(include_input), int(acc), _ptr(out),
                                _stream()), 'hnrf_pe_bwd')
     return out
+
+
+def canonical_bwd(xyz, d_raw, bits, weights):
+    """dX chain of the canonical MLP: returns dZ (8,P,256) and d_xyz (P,3).  bits: sign masks from canonical_train."""
+    lib = _lib.load()
+    _chk(xyz, d_raw, *weights)
+    P = xyz.numel() // 3
+    assert bits.shape == (8, P, 8) and bits.dtype == torch.int32 and bits.is_contiguous()
+    assert d_raw.numel() == 4 * P and len(weights) == 9
+    packed = torch.empty(lib.hnrf_canonical_bwd_packed_bytes() // 4, device=xyz.device)
+    _lib.check(lib.hnrf_canonical_bwd_pack(_ptr_array(weights), _ptr(packed), _stream()), 'hnrf_canonical_bwd_pack')
+    dZ = torch.empty(8, P, 256, device=xyz.device)
+    d_xyz = torch.empty(P, 3, device=xyz.device)
+    _lib.check(lib.hnrf_canonical_bwd(_ptr(xyz), _ptr(d_raw), bits.data_ptr(), _ptr(packed), P, _ptr(dZ), _ptr(d_xyz),
+                                      _stream()), 'hnrf_canonical_bwd')
+    return dZ, d_xyz
+
+
+def nonrigid_bwd(x_skel, hann_w, d_xyz, bits, weights):
+    """dX chain of the non-rigid MLP: returns dZ (6,P,128) and d_x_skel (P,3) (identity path included)."""
+    lib = _lib.load()
+    _chk(x_skel, hann_w, d_xyz, *weights)
+    P = x_skel.numel() // 3
+    assert bits.shape == (6, P, 4) and bits.dtype == torch.int32 and bits.is_contiguous()
+    assert d_xyz.numel() == 3 * P and len(weights) == 7
+    packed = torch.empty(lib.hnrf_nonrigid_bwd_packed_bytes() // 4, device=x_skel.device)
+    _lib.check(lib.hnrf_nonrigid_bwd_pack(_ptr_array(weights), _ptr(packed), _stream()), 'hnrf_nonrigid_bwd_pack')
+    dZ = torch.empty(6, P, 128, device=x_skel.device)
+    d_x_skel = torch.empty(P, 3, device=x_skel.device)
+    _lib.check(lib.hnrf_nonrigid_bwd(_ptr(x_skel), _ptr(hann_w), _ptr(d_xyz), bits.data_ptr(), _ptr(packed), P, _ptr(dZ),
+                                     _ptr(d_x_skel), _stream()), 'hnrf_nonrigid_bwd')
+    return dZ, d_x_skel
 
 
 _dw_ws = {}

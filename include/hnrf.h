@@ -149,18 +149,20 @@ int hnrf_render_rays_fwd(const float* rays_o, const float* rays_d,
 /* =============================== training (backward) ===============================
  * The reference trains through torch.autograd over the ops above (trainer.py:206-220).
  * Here: the forward runs the *_fwd_train variants (HNRF_MLP_F32 only) which also save the
- * positional encodings and the post-ReLU activation matrices; the MLP weight/input
- * gradients are plain library GEMMs on those matrices (dW = dZ^T X, dX = dZ W, done by the
- * host with rocBLAS through torch.mm); the stages around the MLPs have the kernels below. */
+ * positional encodings, the post-ReLU activation matrices and their sign masks; the dX chain of
+ * each MLP is one register-resident kernel (hnrf_*_bwd), the weight gradients come from
+ * hnrf_mlp_dw, and the stages around the MLPs have the kernels below. */
 
 /* pe_out [P,63] (columns in fourier.py order), acts [8][P][256] post-ReLU outputs of
- * pts_linears.{0..14}. */
+ * pts_linears.{0..14}, relu_bits [8][P][8] uint32 (16-byte aligned): the sign masks of acts in the
+ * register order of hnrf_canonical_bwd (opaque to the caller). */
 int hnrf_canonical_fwd_train(const float* xyz, const void* packed, int mode, int64_t P,
-                             float* raw, float* pe_out, float* acts, void* stream);
-/* pe_out [P,36] (hannw_fourier.py order, window weights applied), acts [6][P][128]. */
+                             float* raw, float* pe_out, float* acts, uint32_t* relu_bits, void* stream);
+/* pe_out [P,36] (hannw_fourier.py order, window weights applied), acts [6][P][128],
+ * relu_bits [6][P][4] uint32. */
 int hnrf_nonrigid_fwd_train(const float* x_skel, const float* hann_w, const void* packed,
                             int mode, int64_t P, float* xyz, float* offsets,
-                            float* pe_out, float* acts, void* stream);
+                            float* pe_out, float* acts, uint32_t* relu_bits, void* stream);
 
 /* Backward of hnrf_composite_fwd w.r.t. raw and fg_mask (autograd of network.py:355-379).
  *  g_rgb [R,3]; g_alpha, g_depth [R] or NULL.  Outputs d_raw [R,S,4], d_mask [R,S]. */
@@ -191,12 +193,31 @@ int hnrf_sample_warp_bwd(const float* rays_o, const float* rays_d, const float* 
  * canonical_mlps/mlp_rgb_sigma.py and non_rigid_motion_mlps/mlp_offset.py under trainer.py:139-170):
  *   dW[o][i] = sum_s dZ[s][o] X[s][i]  for o < n_out, i < n_in;   db[o] = sum_s dZ[s][o]  (db may be NULL).
  *  dZ [P, ldz >= n_out], X [P, ldx >= n_in] row-major fp32; dW written with row stride ldw (so the two
- *  column blocks of a skip layer's weight are two calls).  Built shapes: n_out 128 | 256;
- *  n_in 128 | 256 (X 16-byte aligned, ldx % 4 == 0) or n_in <= 64 (any ldx: the PE matrices).
+ *  column blocks of a skip layer's weight are two calls).  Built shapes: n_out 128 | 256 with
+ *  n_in 128 | 256 (X 16-byte aligned, ldx % 4 == 0) or n_in <= 64 (any ldx: the PE matrices);
+ *  n_out <= 4 (the sigma/rgb and offset heads) with n_in 128 | 256.
  *  fp32 MFMA, deterministic (fixed-order slice reduction).  workspace: hnrf_mlp_dw_workspace_bytes. */
 size_t hnrf_mlp_dw_workspace_bytes(int64_t P, int n_out, int n_in);
 int hnrf_mlp_dw(const float* dZ, int64_t ldz, const float* X, int64_t ldx, int64_t P, int n_out, int n_in,
                 float* dW, int64_t ldw, float* db, void* workspace, size_t workspace_bytes, void* stream);
+
+/* Backward through all layers of one MLP (the dX chain of autograd over mlp_rgb_sigma.py / mlp_offset.py),
+ * register-resident like the forward, with the backward of the positional encoding fused.
+ *  *_bwd_pack: transposed weight image from the same nn.Linear weights hnrf_*_pack takes (re-pack after
+ *  every parameter update).
+ *  canonical: xyz [P,3], d_raw [P,4] (16-byte aligned), relu_bits [8][P][8] from hnrf_canonical_fwd_train ->
+ *    dZ [8][P][256] (gradient at every hidden layer's pre-activation: the dZ operand of hnrf_mlp_dw) and
+ *    d_xyz [P,3].
+ *  non-rigid: x_skel [P,3], hann_w [6], d_xyz [P,3], relu_bits [6][P][4] from hnrf_nonrigid_fwd_train ->
+ *    dZ [6][P][128] and d_x_skel [P,3] = d_xyz + J_offset^T d_xyz  (xyz = x_skel + offset, network.py:518-530). */
+size_t hnrf_canonical_bwd_packed_bytes(void);
+size_t hnrf_nonrigid_bwd_packed_bytes(void);
+int hnrf_canonical_bwd_pack(const float* const* weights, void* packed, void* stream);
+int hnrf_nonrigid_bwd_pack(const float* const* weights, void* packed, void* stream);
+int hnrf_canonical_bwd(const float* xyz, const float* d_raw, const uint32_t* relu_bits, const void* packed,
+                       int64_t P, float* dZ, float* d_xyz, void* stream);
+int hnrf_nonrigid_bwd(const float* x_skel, const float* hann_w, const float* d_xyz, const uint32_t* relu_bits,
+                      const void* packed, int64_t P, float* dZ, float* d_x_skel, void* stream);
 
 #ifdef __cplusplus
 }

@@ -10,7 +10,7 @@ def bench(f, n=5):
     for _ in range(n): f()
     torch.cuda.synchronize(); return (time.perf_counter() - t) / n * 1e3
 for P in (1000, 786432):
-    for n_out, n_in, ldx in ((256, 256, 256), (256, 63, 63), (128, 128, 128), (128, 36, 36), (256, 128, 128), (128, 256, 256)):
+    for n_out, n_in, ldx in ((256, 256, 256), (256, 63, 63), (128, 128, 128), (128, 36, 36), (256, 128, 128), (128, 256, 256), (4, 256, 256), (3, 128, 128)):
         dZ = torch.randn(P, n_out, device=dev) * (torch.rand(P, n_out, device=dev) > 0.5)
         X = torch.relu(torch.randn(P, ldx, device=dev))
         ref_w = (dZ.double().t() @ X.double()); ref_b = dZ.double().sum(0)

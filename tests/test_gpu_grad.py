@@ -148,10 +148,105 @@ def test_training_forward_equals_inference_forward():
     bs = [T(st[f'cnl_mlp.module.pts_linears.{i}.bias']) for i in idx] + [T(st['cnl_mlp.module.output_linear.0.bias'])]
     packed = ops.canonical_pack(ws, bs, 'f32')
     raw = ops.canonical(T(xyz), packed, 'f32')
-    raw_t, pe, acts = ops.canonical_train(T(xyz), packed)
+    raw_t, pe, acts, bits = ops.canonical_train(T(xyz), packed)
+    assert bits.shape == (8, P, 8)
     assert torch.equal(raw, raw_t)
     pe_ref = oracle.fourier_pe(torch.from_numpy(xyz), 10)
     assert (pe.cpu() - pe_ref).abs().max() <= 1e-6
     h = torch.relu(torch.nn.functional.linear(pe_ref, torch.from_numpy(st['cnl_mlp.module.pts_linears.0.weight']),
                                               torch.from_numpy(st['cnl_mlp.module.pts_linears.0.bias'])))
     assert (acts[0].cpu() - h).abs().max() <= 1e-5
+
+
+def _torch_mlp(x_in, ws, bs, skip_layer, skip_order, pe_fn, masks):
+    """Plain torch restatement of mlp_rgb_sigma.py:132-198 / mlp_offset.py forward on a PE function.
+    relu(z) is applied as z * masks[l] with the sign pattern of the GPU forward, so that a pre-activation
+    within rounding of zero cannot make the two gradients differ by a whole term."""
+    pe = pe_fn(x_in)
+    h = pe
+    for l in range(len(ws) - 1):
+        if l == skip_layer:
+            h = torch.cat([pe, h], -1) if skip_order == 'pe_first' else torch.cat([h, pe], -1)
+        h = torch.nn.functional.linear(h, ws[l], bs[l]) * masks[l]
+    return torch.nn.functional.linear(h, ws[-1], bs[-1])
+
+
+def test_canonical_backward_chain_and_weight_gradients_match_autograd():
+    """hnrf_canonical_bwd (dX chain + fused PE') and hnrf_mlp_dw against torch.autograd of the same MLP
+    (fp64 on the CPU): dZ of every layer, d_xyz, and every dW / db."""
+    from humannerf_amd import ops
+    from humannerf_amd.autograd import _weight_grads
+    from oracle import oracle
+    from tests.test_gpu_parity import _mlp_states
+    rs = np.random.RandomState(11)
+    st = _mlp_states(rs)
+    P = 777                                                    # ragged: not a multiple of 32 / 128
+    xyz = rs.uniform(-1.2, 1.2, (P, 3)).astype(np.float32)
+    g_raw = (rs.standard_normal((P, 4)) * (rs.uniform(size=(P, 1)) > 0.3)).astype(np.float32)
+    idx = [0, 2, 4, 6, 8, 10, 12, 14]
+    names = [f'cnl_mlp.module.pts_linears.{i}' for i in idx] + ['cnl_mlp.module.output_linear.0']
+    T = lambda a: torch.from_numpy(a).to(dev())
+    ws, bs = [T(st[n + '.weight']) for n in names], [T(st[n + '.bias']) for n in names]
+    raw, pe, acts, bits = ops.canonical_train(T(xyz), ops.canonical_pack(ws, bs, 'f32'))
+    dZ, d_xyz = ops.canonical_bwd(T(xyz), T(g_raw), bits, ws)
+    gW, gb = _weight_grads(dZ, acts, pe, T(g_raw), ws, skip_layer=5, skip_order='pe_first')
+
+    x64 = torch.from_numpy(xyz).double().requires_grad_(True)
+    w64 = [torch.from_numpy(st[n + '.weight']).double().requires_grad_(True) for n in names]
+    b64 = [torch.from_numpy(st[n + '.bias']).double().requires_grad_(True) for n in names]
+    masks = [(acts[l] > 0).double().cpu() for l in range(8)]
+    out = _torch_mlp(x64, w64, b64, 5, 'pe_first', lambda x: oracle.fourier_pe(x, 10), masks)
+    out.backward(torch.from_numpy(g_raw).double())
+    rel = lambda a, b: float((a.double().cpu() - b).abs().max() / b.abs().max().clamp_min(1e-30))
+    assert rel(d_xyz, x64.grad) <= 2e-5
+    for l in range(9):
+        assert rel(gW[l], w64[l].grad) <= 2e-5, l
+        assert rel(gb[l], b64[l].grad) <= 2e-5, l
+
+
+def test_nonrigid_backward_chain_and_weight_gradients_match_autograd():
+    """hnrf_nonrigid_bwd + hnrf_mlp_dw against torch.autograd (fp64): d_x_skel includes the identity path of
+    xyz = x_skel + offset, the Hann window weights scale the PE gradient, the condition code enters layer 0."""
+    from humannerf_amd import ops
+    from humannerf_amd.autograd import _weight_grads
+    from oracle import oracle
+    from tests.test_gpu_parity import _mlp_states
+    rs = np.random.RandomState(12)
+    st = _mlp_states(rs)
+    P = 1000
+    x = rs.uniform(-1.0, 1.0, (P, 3)).astype(np.float32)
+    g_xyz = rs.standard_normal((P, 3)).astype(np.float32)
+    cond = (rs.standard_normal(69) * 0.3).astype(np.float32)
+    hann = np.array([1.0, 1.0, 0.75, 0.25, 0.0, 0.0], np.float32)
+    names = [f'non_rigid_mlp.module.block_mlps.{i}' for i in (0, 2, 4, 6, 8, 10, 12)]
+    T = lambda a: torch.from_numpy(a).to(dev())
+    ws, bs = [T(st[n + '.weight']) for n in names], [T(st[n + '.bias']) for n in names]
+    xyz, off, pe, acts, bits = ops.nonrigid_train(T(x), T(hann), ops.nonrigid_pack(ws, bs, T(cond), 'f32'))
+    dZ, d_x = ops.nonrigid_bwd(T(x), T(hann), T(g_xyz), bits, ws)
+    gW, gb = _weight_grads(dZ, acts, pe, T(g_xyz), ws, skip_layer=4, skip_order='h_first')
+    gW[0] = torch.cat([gb[0][:, None] * T(cond).reshape(1, -1), gW[0]], dim=1)
+
+    x64 = torch.from_numpy(x).double().requires_grad_(True)
+    w64 = [torch.from_numpy(st[n + '.weight']).double().requires_grad_(True) for n in names]
+    b64 = [torch.from_numpy(st[n + '.bias']).double().requires_grad_(True) for n in names]
+    c64, h64 = torch.from_numpy(cond).double(), torch.from_numpy(hann).double()
+
+    def pe_fn(xx):
+        bands = []
+        for k in range(6):
+            bands += [h64[k] * torch.sin(xx * 2.0 ** k), h64[k] * torch.cos(xx * 2.0 ** k)]
+        return torch.cat(bands, -1)
+    pe64 = pe_fn(x64)
+    h = torch.cat([c64.expand(P, 69), pe64], -1)
+    for l in range(6):
+        if l == 4:
+            h = torch.cat([h, pe64], -1)
+        h = torch.nn.functional.linear(h, w64[l], b64[l]) * (acts[l] > 0).double().cpu()
+    out = x64 + torch.nn.functional.linear(h, w64[6], b64[6])
+    out.backward(torch.from_numpy(g_xyz).double())
+    rel = lambda a, b: float((a.double().cpu() - b).abs().max() / b.abs().max().clamp_min(1e-30))
+    assert (xyz.double().cpu() - out.detach()).abs().max() <= 1e-5
+    assert rel(d_x, x64.grad) <= 2e-5
+    for l in range(7):
+        assert rel(gW[l], w64[l].grad) <= 2e-5, l
+        assert rel(gb[l], b64[l].grad) <= 2e-5, l
