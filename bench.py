@@ -47,6 +47,9 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-rays', type=int, default=4096)
     ap.add_argument('--train-steps', type=int, default=10, help='extra: timed training iterations (0 = skip)')
+    ap.add_argument('--main-only', action='store_true',
+                    help='only the headline loop (no other-mode / culled / training / CPU legs): the profiling form, '
+                         'so that a rocprofv3 --stats average covers exactly the launches behind `roofline`')
     args = ap.parse_args()
 
     rank = int(os.environ.get('RANK', 0))
@@ -154,44 +157,46 @@ def main():
                                     / elapsed / 1e12, 2),
     }
 
+    extras = not args.main_only
     # the other MLP arithmetic on the same workload (short run), for reference
     other = 'f32' if args.mode == 'f16x3' else 'f16x3'
-    cfg.amd.mlp_mode = other
-    step()
-    net.mlp_event_log = []
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(2):
+    if extras:
+        cfg.amd.mlp_mode = other
         step()
-    torch.cuda.synchronize()
-    dt_o = time.perf_counter() - t0
-    ko = [a.elapsed_time(b) for a, b in net.mlp_event_log]
-    net.mlp_event_log = None
-    cfg.amd.mlp_mode = args.mode
-    ach_o = flop_per_launch / (float(np.mean(ko)) * 1e-3) / 1e12
-    result['other_mode'] = {'mlp_mode': other, 'rays_per_s_per_gpu': round(R * 2 / dt_o, 1),
-                            'canonical_kernel_tflops': round(ach_o, 2), 'peak': PEAK_TFLOPS[other],
-                            'frac': round(ach_o / PEAK_TFLOPS[other], 4)}
-    result['precision'] = ('both modes pass the same fp32 parity tests against the reference (|d rgb| <= 5e-5); '
-                           'canonical-MLP error vs fp64: f16x3 4.5e-7, f32-MFMA 9e-7, torch-CPU fp32 5e-7 (relative)')
+        net.mlp_event_log = []
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(2):
+            step()
+        torch.cuda.synchronize()
+        dt_o = time.perf_counter() - t0
+        ko = [a.elapsed_time(b) for a, b in net.mlp_event_log]
+        net.mlp_event_log = None
+        cfg.amd.mlp_mode = args.mode
+        ach_o = flop_per_launch / (float(np.mean(ko)) * 1e-3) / 1e12
+        result['other_mode'] = {'mlp_mode': other, 'rays_per_s_per_gpu': round(R * 2 / dt_o, 1),
+                                'canonical_kernel_tflops': round(ach_o, 2), 'peak': PEAK_TFLOPS[other],
+                                'frac': round(ach_o / PEAK_TFLOPS[other], 4)}
+        result['precision'] = ('both modes pass the same fp32 parity tests against the reference (|d rgb| <= 5e-5); '
+                               'canonical-MLP error vs fp64: f16x3 4.5e-7, f32-MFMA 9e-7, torch-CPU fp32 5e-7 (relative)')
 
-    # opt-in sample culling (cfg.amd.cull_eps = 1e-9: bound 2*S*eps = 2.6e-7 on rgb/alpha, ~100x below
-    # the reference's own fp32 noise); reported separately, never as `value`
-    cfg.amd.cull_eps = 1e-9
-    step()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(3):
-        oc = step()
-    torch.cuda.synchronize()
-    dt_c = time.perf_counter() - t0
-    cfg.amd.cull_eps = 0.0
-    result['culled'] = {'cull_eps': 1e-9, 'rays_per_s_per_gpu': round(R * 3 / dt_c, 1),
-                        'max_abs_rgb_diff_vs_dense': float((oc['rgb'] - out['rgb']).abs().max()),
-                        'note': 'samples with fg likelihood < eps skip both MLPs; not the reference arithmetic, '
-                                'error bound 2*S*eps'}
+        # opt-in sample culling (cfg.amd.cull_eps = 1e-9: bound 2*S*eps = 2.6e-7 on rgb/alpha, ~100x below
+        # the reference's own fp32 noise); reported separately, never as `value`
+        cfg.amd.cull_eps = 1e-9
+        step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(3):
+            oc = step()
+        torch.cuda.synchronize()
+        dt_c = time.perf_counter() - t0
+        cfg.amd.cull_eps = 0.0
+        result['culled'] = {'cull_eps': 1e-9, 'rays_per_s_per_gpu': round(R * 3 / dt_c, 1),
+                            'max_abs_rgb_diff_vs_dense': float((oc['rgb'] - out['rgb']).abs().max()),
+                            'note': 'samples with fg likelihood < eps skip both MLPs; not the reference arithmetic, '
+                                    'error bound 2*S*eps'}
 
-    if args.train_steps > 0:
+    if extras and args.train_steps > 0:
         # second metric of BASELINE.json: train iters/s.  One iteration = 6 patches x 32x32 rays x 128
         # samples of this rank's frame (default.yaml:352-357), perturb = 1, loss 0.2*MSE vs a seeded
         # random target (LPIPS-VGG weights cannot be fetched offline), Adam step, gradient all-reduce.
@@ -209,7 +214,7 @@ def main():
         tb['target_rgbs'] = torch.from_numpy(np.random.RandomState(3 + rank).rand(idx.numel(), 3).astype(np.float32)).to(dev)
         trainer = Trainer(net, world_size=world)
         for _ in range(3):
-            trainer.train_step(tb)               # warm-up (allocator growth, rocBLAS solution selection)
+            trainer.train_step(tb)               # warm-up (allocator growth, MIOpen solution search for the decoder)
         torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
@@ -227,13 +232,13 @@ def main():
         assert torch.isfinite(loss)
         result['train'] = {'iters_per_s': round(args.train_steps / tt, 3), 'ms_per_iter': round(tt / args.train_steps * 1e3, 2),
                            'steps': args.train_steps, 'rays_per_iter_per_gpu': int(idx.numel()), 'samples_per_ray': S,
-                           'frames_per_iter': world, 'mlp_arithmetic': 'f32 MFMA forward + rocBLAS f32 backward GEMMs',
+                           'frames_per_iter': world, 'mlp_arithmetic': 'fp32 MFMA: forward, dX chain and dW kernels (no library GEMM on the per-sample path)',
                            'loss': '0.2*MSE on rgb (LPIPS-VGG unavailable offline)',
                            'note': 'reference DataParallel trains 1 frame/iter at any GPU count; here N ranks = N frames/iter'}
         net.eval()
         cfg.perturb = 0.
 
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and extras and not args.no_cpu_baseline:
         # bounded sample of the same workload: every (R/cpu_rays)-th ray of the frame
         from oracle import oracle
         stride = max(1, R // args.cpu_rays)

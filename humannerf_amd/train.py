@@ -39,7 +39,10 @@ def build_optimizer(network):
             groups.append({'params': [value], 'name': key})
     if cfg.train.optimizer != 'adam':
         raise ValueError('Unsupported optimizer ' + str(cfg.train.optimizer))
-    return torch.optim.Adam(groups, lr=cfg.train.lr, betas=(0.9, 0.999))
+    # same per-parameter groups as the reference (optimizer checkpoints stay interchangeable); on the GPU the
+    # update of each group is one fused kernel instead of torch's default chain of foreach kernels
+    fused = all(g['params'][0].is_cuda for g in groups)
+    return torch.optim.Adam(groups, lr=cfg.train.lr, betas=(0.9, 0.999), fused=fused)
 
 
 def update_lr(optimizer, iter_step):
