@@ -62,3 +62,60 @@ def test_hip_path_vs_eager_pytorch_rocm(seeded_params):
     # measured round 1: eager ~0.7-1.2 s/frame; HIP f16x3 ~0.13 s, f32 ~0.35 s
     assert t_eager / res['f16x3'] >= 4.0
     assert t_eager / res['f32'] >= 1.5
+
+
+def test_training_step_vs_eager_pytorch_rocm(seeded_params):
+    """Second metric of BASELINE.json (train iters/s): one optimisation step on 6 144 rays x 128 samples
+    (default.yaml:352-357: 6 patches of 32x32) -- eager torch.autograd through the op-faithful restatement
+    vs the HIP training path (autograd.RenderRays), same Adam step on the same parameters."""
+    from humannerf_amd import scene
+    from humannerf_amd.config import cfg
+    from humannerf_amd.network import Network
+    from humannerf_amd.train import Trainer
+    from oracle import oracle
+    dev = torch.device('cuda:0')
+    fr = scene.synthetic_frame(H=512, W=512, focal_at_512=1700.0)
+    idx = (np.arange(6144) * 37) % (512 * 512)
+    sub = dict(fr)
+    sub['rays'], sub['near'], sub['far'] = fr['rays'][:, idx], fr['near'][idx], fr['far'][idx]
+    target = torch.rand(6144, 3, device=dev)
+
+    state = {k: torch.from_numpy(v).to(dev).requires_grad_(True) for k, v in seeded_params.items()}
+    opt = torch.optim.Adam(list(state.values()), lr=5e-4)
+
+    def eager_step():
+        opt.zero_grad(set_to_none=True)
+        out = oracle.render(state, sub, iter_val=1e7, N_samples=128, device=dev, use_grid_sample=True)
+        loss = 0.2 * torch.mean((out['rgb'] - target) ** 2)
+        loss.backward()
+        opt.step()
+    for _ in range(2):
+        eager_step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(3):
+        eager_step()
+    torch.cuda.synchronize()
+    t_eager = (time.perf_counter() - t0) / 3
+
+    net = Network()
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in seeded_params.items()})
+    net = net.to(dev).train()
+    keys = ['rays', 'near', 'far', 'dst_Rs', 'dst_Ts', 'cnl_gtfms', 'motion_weights_priors', 'dst_posevec',
+            'cnl_bbox_min_xyz', 'cnl_bbox_scale_xyz', 'bgcolor']
+    batch = {k: torch.from_numpy(np.ascontiguousarray(sub[k])).to(dev) for k in keys}
+    batch['target_rgbs'] = target
+    cfg.perturb, cfg.N_samples = 1.0, 128
+    tr = Trainer(net)
+    for _ in range(3):
+        tr.train_step(batch)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(5):
+        tr.train_step(batch)
+    torch.cuda.synchronize()
+    t_hip = (time.perf_counter() - t0) / 5
+    print('\ntraining step: eager PyTorch-ROCm %.1f ms (%.1f it/s), HIP path %.1f ms (%.1f it/s): %.1fx'
+          % (t_eager * 1e3, 1 / t_eager, t_hip * 1e3, 1 / t_hip, t_eager / t_hip))
+    # measured round 1: eager ~150 ms, HIP ~36 ms
+    assert t_eager / t_hip >= 2.0
