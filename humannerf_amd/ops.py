@@ -352,3 +352,32 @@ def nonrigid_sparse(x_skel, hann_w, packed, idx, count, mode='f32'):
     _lib.check(lib.hnrf_nonrigid_fwd_sparse(_ptr(x_skel), _ptr(hann_w), _ptr(packed), MLP_MODES[mode], P, _ptr(idx),
                                             _ptr(count), _ptr(xyz), 0, _stream()), 'hnrf_nonrigid_fwd_sparse')
     return xyz
+
+
+def gen_rays(K, E, bbox_min, bbox_max, H, W, device=None):
+    """Rays of one camera that cross the bbox, generated on the device in pixel order.
+
+    K (3,3), E (4,4) float32 arrays / tensors (intrinsics, world->camera extrinsics), bbox_min / bbox_max (3,).
+    Returns dict(rays (3,N,3) = [o, d, d], near (N,1), far (N,1), ray_mask (H*W,) bool) -- the per-frame entries a
+    reference dataset yields (freeview.py:232-242).  One host sync (the ray count sizes the views)."""
+    lib = _lib.load()
+    import numpy as np
+    device = device or torch.device('cuda', torch.cuda.current_device())
+    K = np.asarray(K.cpu() if torch.is_tensor(K) else K, dtype=np.float32)
+    E = np.asarray(E.cpu() if torch.is_tensor(E) else E, dtype=np.float32)
+    small = np.concatenate([np.linalg.inv(K).reshape(-1), E[:3, :3].reshape(-1), E[:3, 3].reshape(-1),
+                            np.asarray(bbox_min, np.float32).reshape(-1), np.asarray(bbox_max, np.float32).reshape(-1)])
+    cam = torch.from_numpy(small.astype(np.float32)).to(device)
+    n = H * W
+    rays_o, rays_d = torch.empty(n, 3, device=device), torch.empty(n, 3, device=device)
+    near, far = torch.empty(n, device=device), torch.empty(n, device=device)
+    mask = torch.empty(n, dtype=torch.uint8, device=device)
+    count = torch.empty(1, dtype=torch.int32, device=device)
+    ws = torch.empty(lib.hnrf_gen_rays_workspace_bytes(H, W), dtype=torch.uint8, device=device)
+    base = cam.data_ptr()
+    _lib.check(lib.hnrf_gen_rays(base, base + 36, base + 72, base + 84, base + 96, H, W, _ptr(rays_o), _ptr(rays_d),
+                                 _ptr(near), _ptr(far), mask.data_ptr(), count.data_ptr(), ws.data_ptr(), ws.numel(),
+                                 _stream()), 'hnrf_gen_rays')
+    N = int(count.item())
+    o, d = rays_o[:N], rays_d[:N]
+    return {'rays': torch.stack([o, d, d], 0), 'near': near[:N, None], 'far': far[:N, None], 'ray_mask': mask.bool()}

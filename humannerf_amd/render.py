@@ -37,7 +37,12 @@ def render_frames(network, frames, rank=0, world=1, device=None, on_image=None):
     """Render ``frames`` (sequence of per-frame input dicts, numpy or tensors) frame-sharded.
 
     Returns {frame_idx: uint8 rgb image on the host} for this rank's frames.  ``on_image(idx, rgb8,
-    alpha8)`` is called as images arrive (e.g. a PNG writer thread)."""
+    alpha8)`` is called as images arrive (e.g. a PNG writer thread).
+
+    A frame may carry its camera instead of precomputed rays -- ``K`` (3,3), ``E`` (4,4), ``cnl_bbox_max_xyz`` next to
+    ``img_width`` / ``img_height`` and no ``rays``: the rays, near/far and ray_mask are then generated on the
+    device (ops.gen_rays = get_rays_from_KRT + rays_intersect_3d_bbox, freeview.py:220-230) instead of the
+    per-frame numpy pass and the 32 B/ray upload."""
     device = device or next(network.parameters()).device
     network.eval()
     keys = ('rays', 'near', 'far', 'dst_Rs', 'dst_Ts', 'cnl_gtfms', 'motion_weights_priors', 'dst_posevec',
@@ -50,6 +55,11 @@ def render_frames(network, frames, rank=0, world=1, device=None, on_image=None):
     try:
         for idx in hdist.frame_shard(len(frames), rank, world):
             fr = frames[idx]
+            if 'rays' not in fr:
+                from . import ops
+                fr = dict(fr)
+                fr.update(ops.gen_rays(fr['K'], fr['E'], fr['cnl_bbox_min_xyz'], fr['cnl_bbox_max_xyz'],
+                                       int(fr['img_height']), int(fr['img_width']), device=device))
             data = {k: torch.as_tensor(np.ascontiguousarray(fr[k]) if isinstance(fr[k], np.ndarray) else fr[k]).to(device)
                     for k in keys}
             with torch.no_grad():

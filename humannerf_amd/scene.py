@@ -199,7 +199,7 @@ def tpose_camera(img_size, radius=6.0, focal=1250.0):
 
 def synthetic_frame(H=512, W=512, pose_seed=0, pose_scale=0.2, focal_at_512=1700.0,
                     bbox_offset=0.3, volume_size=32, bgcolor=(0.0, 0.0, 0.0),
-                    ray_stride=1):
+                    ray_stride=1, camera_only=False):
     """The synthetic frame of SURVEY.md Appendix A.2 / section 8(d).
 
     Returns the numpy dict a reference dataset would yield for one frame
@@ -207,6 +207,8 @@ def synthetic_frame(H=512, W=512, pose_seed=0, pose_scale=0.2, focal_at_512=1700
     pixel ray hit the canonical bbox so that R == H*W exactly; 1250 is the
     T-pose renderer's framing (about 88 % of the pixels hit).
     ``ray_stride`` sub-samples the pixel grid (golden fixtures use few rays).
+    ``camera_only``: leave out rays / near / far / ray_mask and return the camera (K, E) instead, for
+    the device-side ray generator.
     """
     J = TPOSE_JOINTS
     mn, mx = J.min(0) - bbox_offset, J.max(0) + bbox_offset
@@ -219,6 +221,19 @@ def synthetic_frame(H=512, W=512, pose_seed=0, pose_scale=0.2, focal_at_512=1700
 
     K, E = tpose_camera(np.array([W, H], dtype=np.float32), 6.0,
                         focal_at_512 * H / 512.0)
+    common = {
+        'dst_Rs': dst_Rs, 'dst_Ts': dst_Ts, 'cnl_gtfms': cnl_gtfms,
+        'motion_weights_priors': priors,
+        'dst_posevec': dst_posevec,
+        'cnl_bbox_min_xyz': mn.astype(np.float32),
+        'cnl_bbox_max_xyz': mx.astype(np.float32),
+        'cnl_bbox_scale_xyz': (2.0 / (mx - mn)).astype(np.float32),
+        'bgcolor': np.array(bgcolor, dtype=np.float32),
+        'img_width': W, 'img_height': H,
+    }
+    if camera_only:
+        assert ray_stride == 1
+        return dict(common, K=K, E=E)
     rays_o, rays_d = get_rays_from_KRT(H, W, K, E[:3, :3], E[:3, 3])
     rays_o = rays_o[::ray_stride, ::ray_stride].reshape(-1, 3).astype(np.float32)
     rays_d = rays_d[::ray_stride, ::ray_stride].reshape(-1, 3).astype(np.float32)
@@ -230,12 +245,5 @@ def synthetic_frame(H=512, W=512, pose_seed=0, pose_scale=0.2, focal_at_512=1700
         'near': near[:, None].astype(np.float32),
         'far': far[:, None].astype(np.float32),
         'ray_mask': hit,
-        'dst_Rs': dst_Rs, 'dst_Ts': dst_Ts, 'cnl_gtfms': cnl_gtfms,
-        'motion_weights_priors': priors,
-        'dst_posevec': dst_posevec,
-        'cnl_bbox_min_xyz': mn.astype(np.float32),
-        'cnl_bbox_max_xyz': mx.astype(np.float32),
-        'cnl_bbox_scale_xyz': (2.0 / (mx - mn)).astype(np.float32),
-        'bgcolor': np.array(bgcolor, dtype=np.float32),
-        'img_width': W, 'img_height': H,
+        **common,
     }

@@ -219,6 +219,19 @@ int hnrf_canonical_bwd(const float* xyz, const float* d_raw, const uint32_t* rel
 int hnrf_nonrigid_bwd(const float* x_skel, const float* hann_w, const float* d_xyz, const uint32_t* relu_bits,
                       const void* packed, int64_t P, float* dZ, float* d_x_skel, void* stream);
 
+/* =============================== in front of the path ===============================
+ * Ray generation + bbox intersection + order-preserving compaction (get_rays_from_KRT,
+ * core/utils/camera_util.py:132-159; rays_intersect_3d_bbox, camera_util.py:162-208; called per frame at
+ * core/data/human_nerf/freeview.py:220-230 and its siblings).
+ *  Kinv [3,3] = inverse intrinsics, R [3,3], T [3] = extrinsics, bbox_min / bbox_max [3] (unpadded; the 1 cm pad
+ *  is applied inside), all float32 device pointers.  Outputs, in pixel order: ray_mask [H*W] (1 = the ray crosses
+ *  the box), and for the *count kept rays rays_o / rays_d [count,3] (direction un-normalised, components clamped
+ *  to 1e-5 like the reference), near / far [count].  Size the ray buffers for H*W. */
+size_t hnrf_gen_rays_workspace_bytes(int H, int W);
+int hnrf_gen_rays(const float* Kinv, const float* R, const float* T, const float* bbox_min, const float* bbox_max,
+                  int H, int W, float* rays_o, float* rays_d, float* near, float* far, uint8_t* ray_mask,
+                  int* count, void* workspace, size_t workspace_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -342,6 +342,17 @@ def test_render_frames_driver(gpu_net):
         assert (img[~miss] < 255).any()
     x = torch.rand(10, 3)
     assert abs(float(render.psnr(x, x + 0.1)) - 20.0) < 1e-4
+    # frames that carry the camera instead of host-made rays: generated on the device, same images
+    cams = [scene.synthetic_frame(H=48, W=48, focal_at_512=1250.0, pose_seed=s, bgcolor=(255., 255., 255.),
+                                  camera_only=True) for s in range(3)]
+    cfg.amd.diagnostics = False
+    try:
+        imgs_c = render.render_frames(gpu_net, cams, rank=0, world=1)
+    finally:
+        cfg.amd.diagnostics = True
+    for i in range(3):
+        ref = (imgs0 if i % 2 == 0 else imgs1)[i]
+        assert np.abs(imgs_c[i].astype(np.int32) - ref.astype(np.int32)).max() <= 1
 
 
 def test_ray_chunking_is_invisible(gpu_net, golden_frame):
@@ -381,3 +392,30 @@ def test_c5_sized_samples_per_ray(gpu_net, golden_frame):
     for k in lean:
         assert torch.equal(lean[k], full[k])
     assert float((full['alpha'] - s128['alpha']).abs().mean()) < 0.02
+
+
+@pytest.mark.parametrize('H,W,focal', [(64, 64, 1700.0), (120, 96, 1250.0), (512, 512, 1250.0), (37, 53, 600.0)])
+def test_ray_generation_kernel(H, W, focal):
+    """hnrf_gen_rays vs the numpy restatement of get_rays_from_KRT + rays_intersect_3d_bbox (scene.py, itself
+    pinned to the reference's helpers by tests/golden): same hit mask, rays in pixel order, near/far.
+    Tolerance: the float32 ray arithmetic may differ from numpy's BLAS by an ulp (summation order), near/far are
+    float64 functions of those rays."""
+    from humannerf_amd import ops, scene
+    J = scene.TPOSE_JOINTS
+    mn, mx = (J.min(0) - 0.3).astype(np.float32), (J.max(0) + 0.3).astype(np.float32)
+    K, E = scene.tpose_camera(np.array([W, H], dtype=np.float32), 6.0, focal * H / 512.0)
+    ro, rd = scene.get_rays_from_KRT(H, W, K, E[:3, :3], E[:3, 3])
+    ro, rd = ro.reshape(-1, 3).astype(np.float32), rd.reshape(-1, 3).astype(np.float32).copy()
+    near, far, hit = scene.rays_intersect_3d_bbox(np.stack([mn, mx]), ro, rd)
+    got = ops.gen_rays(K, E, mn, mx, H, W)
+    gm = got['ray_mask'].cpu().numpy()
+    # rays grazing an edge may flip with an ulp of difference in d: none do on these cameras
+    assert gm.shape == hit.shape and (gm != hit).sum() == 0
+    assert got['rays'].shape == (3, int(hit.sum()), 3)
+    np.testing.assert_allclose(got['rays'][0].cpu().numpy(), ro[hit], rtol=0, atol=1e-6)
+    np.testing.assert_allclose(got['rays'][1].cpu().numpy(), rd[hit], rtol=2e-6, atol=2e-6)
+    assert torch.equal(got['rays'][1], got['rays'][2])
+    np.testing.assert_allclose(got['near'][:, 0].cpu().numpy(), near.astype(np.float32), rtol=2e-6, atol=2e-6)
+    np.testing.assert_allclose(got['far'][:, 0].cpu().numpy(), far.astype(np.float32), rtol=2e-6, atol=2e-6)
+    if focal < 1700.0:
+        assert 0 < hit.sum() < H * W                          # the compaction really dropped pixels
