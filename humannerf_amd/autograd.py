@@ -1,7 +1,7 @@
 """torch.autograd glue for training through the HIP path.
 
 ``RenderRays`` is one differentiable op = Network._render_rays (network.py:474-602) for one
-ray chunk.  Forward: K1, K2/K3 in their activation-saving variants, K4.  Backward: K4',
+ray chunk.  Forward: K1, K2/K3 in their activation-saving variants (cfg.amd.train_mlp_mode), K4.  Backward: K4',
 for the two MLPs the register-resident dX chain (hnrf_*_bwd: relu' from the saved
 post-activations, PE' fused) and hnrf_mlp_dw (dW = dZ^T X and db, one workgroup per CU
 holding the whole output), K1'.  No library GEMM is left on the per-sample path.  Gradients are produced for the motion
@@ -11,6 +11,7 @@ reference's four parameter groups receive gradient (last 
 import torch
 
 from . import ops
+from .config import amd_option
 
 
 def _weight_grads(dZ, acts, pe, dY, weights, skip_layer, skip_order):
@@ -45,13 +46,14 @@ class RenderRays(torch.autograd.Function):
         motion_Rs, motion_Ts, vol = motion_Rs.contiguous(), motion_Ts.contiguous(), vol.contiguous()
         z, x_skel, mask, _ = ops.sample_warp(rays_o, rays_d, near, far, t_rand, motion_Rs, motion_Ts, vol, bbox_min,
                                              bbox_scale, n_samples, want_bmw=False)
+        mode = amd_option('train_mlp_mode', 'f16x3')
         if use_nonrigid:
-            nr_packed = ops.nonrigid_pack(nr_w, nr_b, cond, 'f32')
-            xyz, _, pe_n, acts_n, bits_n = ops.nonrigid_train(x_skel, hann_w, nr_packed)
+            nr_packed = ops.nonrigid_pack(nr_w, nr_b, cond, mode)
+            xyz, _, pe_n, acts_n, bits_n = ops.nonrigid_train(x_skel, hann_w, nr_packed, mode)
         else:
             xyz, pe_n, acts_n, bits_n = x_skel, None, None, None
-        cn_packed = ops.canonical_pack(cn_w, cn_b, 'f32')
-        raw, pe_c, acts_c, bits_c = ops.canonical_train(xyz, cn_packed)
+        cn_packed = ops.canonical_pack(cn_w, cn_b, mode)
+        raw, pe_c, acts_c, bits_c = ops.canonical_train(xyz, cn_packed, mode)
         out = ops.composite(raw, mask, z, rays_d, None, bg, diagnostics=False)
         ctx.use_nonrigid = use_nonrigid
         ctx.save_for_backward(rays_o, rays_d, z, x_skel, mask, xyz, raw, pe_c, acts_c, pe_n, acts_n, motion_Rs,

@@ -116,8 +116,10 @@ _DEFAULTS = {
         # arithmetic of the two per-sample MLPs (inference): 'f16x3' = fp32-equivalent
         # split-f16 (hi+lo) operands, 3 f16 MFMAs, fp32 accumulate -- passes the same
         # parity tests as 'f32' = v_mfma_f32_32x32x2_f32 (bitwise an fp32 fma chain),
-        # at 2.7x the speed.  Training always uses the f32 kernels.
+        # at 3x the speed.
         'mlp_mode': 'f16x3',
+        # arithmetic of the activation-saving training forward (the backward kernels are fp32 MFMA either way)
+        'train_mlp_mode': 'f16x3',
         # materialise the per-sample diagnostic outputs the reference always
         # returns (backward_motion_weights, xyz_on_rays, ...; ~17 KB/ray).
         'diagnostics': True,

@@ -176,13 +176,15 @@ __device__ __forceinline__ void slab_issue(const char* gsrc, unsigned lds_addr, 
 
 // wait until at most `keep` of this wave's DMA pieces are still in flight
 __device__ __forceinline__ void wait_dma_keep(int keep) {
+#define HNRF_VMCNT_CASE(N) case N: asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory"); break;
     switch (keep) {
-        case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
-        case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
-        case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
-        case 10: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
+        HNRF_VMCNT_CASE(4) HNRF_VMCNT_CASE(6) HNRF_VMCNT_CASE(8) HNRF_VMCNT_CASE(10)
+        // training variant: the 4 activation stores per finished tile sit in the same in-order queue
+        HNRF_VMCNT_CASE(12) HNRF_VMCNT_CASE(14) HNRF_VMCNT_CASE(16) HNRF_VMCNT_CASE(18) HNRF_VMCNT_CASE(20)
+        HNRF_VMCNT_CASE(22) HNRF_VMCNT_CASE(24) HNRF_VMCNT_CASE(26)
         default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
     }
+#undef HNRF_VMCNT_CASE
 }
 
 __device__ __forceinline__ void tile_sync(int keep) {
@@ -246,6 +248,50 @@ __device__ __forceinline__ void epi_pair(const f32x16& a1, const f32x16& a2, int
     lo[e + 1] = ll[1];
 }
 
+// epi_pair that also hands back the two activations (training variant stores them)
+template <bool RELU>
+__device__ __forceinline__ void epi_pair_x(const f32x16& a1, const f32x16& a2, int i, h16x8& hi, h16x8& lo, float& x0o,
+                                           float& x1o) {
+    float x0 = fmaf(a2[2 * i], LO_INV, a1[2 * i]);
+    float x1 = fmaf(a2[2 * i + 1], LO_INV, a1[2 * i + 1]);
+    if (RELU) {
+        x0 = __builtin_amdgcn_fmed3f(x0, 0.f, 65504.f);
+        x1 = __builtin_amdgcn_fmed3f(x1, 0.f, 65504.f);
+    }
+    const h16x2 hh = __builtin_convertvector(f32x2{x0, x1}, h16x2);
+    const float r0 = fmaf(x0, LO_SCALE, -((float)hh[0] * LO_SCALE));
+    const float r1 = fmaf(x1, LO_SCALE, -((float)hh[1] * LO_SCALE));
+    const h16x2 ll = __builtin_convertvector(f32x2{r0, r1}, h16x2);
+    const int e = 2 * (i & 3);
+    hi[e] = hh[0];
+    hi[e + 1] = hh[1];
+    lo[e] = ll[0];
+    lo[e + 1] = ll[1];
+    x0o = x0;
+    x1o = x1;
+}
+
+// Training variant (SAVE): where this lane's activations go.  row = the lane's row of the layer's [P, width]
+// fp32 activation matrix (+ 4 h floats: the lane half's column offset), bits = its words of the sign mask.
+// EVERY lane stores (lanes past P carry a copy of sample P-1 and rewrite its values): the number of VMEM
+// operations per tile must be the same for all waves, the hand-counted vmcnt waits include them.
+struct SaveCtx {
+    float* row;
+    uint32_t* bits;
+    float sv0, sv1;            // even pair of the current float4
+};
+
+template <int NW>
+__device__ __forceinline__ void save_pair(SaveCtx& sc, uint32_t (&bw)[NW], int t, int i, float x0, float x1) {
+    bw[t >> 1] |= ((x0 > 0.f ? 1u : 0u) | (x1 > 0.f ? 2u : 0u)) << (16 * (t & 1) + 2 * i);
+    if (i & 1) {
+        *reinterpret_cast<f32x4*>(sc.row + 32 * t + 8 * (i >> 1)) = f32x4{sc.sv0, sc.sv1, x0, x1};
+    } else {
+        sc.sv0 = x0;
+        sc.sv1 = x1;
+    }
+}
+
 // One layer.  K order = [PE part (NKA k-steps, B operand from the LDS stash) | hidden part
 // (NKB k-steps, B operand from registers)].  The layer's NT tiles travel TPS per slab.
 // nb1 / nb2: blocks of the first / second slab that follow this layer in the image (0 = none).
@@ -256,9 +302,9 @@ __device__ __forceinline__ void epi_pair(const f32x16& a1, const f32x16& a2, int
 //     96 cycles of one k-step's MFMAs);
 //   * the VALU epilogue of tile t-1 (8 pair-units) is spread over the k-steps of tile t,
 //     so it runs in the shadow of the MFMAs; only the last tile's epilogue is exposed.
-template <int NT, int TPS, int NKA, int NKB, bool RELU, int NB, int NO>
+template <int NT, int TPS, int NKA, int NKB, bool RELU, bool SAVE = false, int NB, int NO>
 __device__ __forceinline__ void layer16(Pipe& p, int nb1, int nb2, const h16x8 (&bh)[NB], const h16x8 (&bl)[NB],
-                                        h16x8 (&oh)[NO], h16x8 (&ol)[NO], float (&last)[16]) {
+                                        h16x8 (&oh)[NO], h16x8 (&ol)[NO], float (&last)[16], SaveCtx* sc = nullptr) {
     static_assert(NB >= (NKB > 0 ? NKB : 1) && NO >= 2 * NT && NT % TPS == 0, "bad layer shape");
     constexpr int NK = NKA + NKB;
     constexpr int NBLK = 2 * NK;             // blocks per tile
@@ -267,6 +313,9 @@ __device__ __forceinline__ void layer16(Pipe& p, int nb1, int nb2, const h16x8 (
     static_assert((NBLK * TPS) % 4 == 0, "every wave must issue the same number of DMA pieces per slab");
     f32x16 pacc1 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     f32x16 pacc2 = pacc1;                    // accumulators of the previous tile (epilogue pending)
+    uint32_t bw[(NT + 1) / 2];               // SAVE: sign mask of this layer's outputs (this lane half)
+#pragma unroll
+    for (int i = 0; i < (NT + 1) / 2; ++i) bw[i] = 0u;
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
         // slab n+2 -> ring slot (ph + 2) % RING (last read during step n-1: fenced by the previous barrier)
@@ -346,6 +395,12 @@ __device__ __forceinline__ void layer16(Pipe& p, int nb1, int nb2, const h16x8 (
 #pragma unroll
                     for (int i = 0; i < 8; ++i)
                         if ((i * NK) / 8 == ks) {
+                            if constexpr (SAVE) {
+                                float x0, x1;
+                                epi_pair_x<RELU>(pacc1, pacc2, i, oh[2 * (t - 1) + (i >> 2)], ol[2 * (t - 1) + (i >> 2)],
+                                                 x0, x1);
+                                save_pair(*sc, bw, t - 1, i, x0, x1);
+                            } else
                             epi_pair<RELU>(pacc1, pacc2, i, oh[2 * (t - 1) + (i >> 2)], ol[2 * (t - 1) + (i >> 2)]);
                             // pin the result here: without a use in this block hipcc sinks the whole
                             // epilogue to the first consumer (the next layer), out of the MFMA shadow
@@ -370,8 +425,11 @@ __device__ __forceinline__ void layer16(Pipe& p, int nb1, int nb2, const h16x8 (
             pacc1 = acc1;
             pacc2 = acc2;
         }
-        // slab n+1 landed (only the pieces of slab n+2 may still fly); every wave done with slab n
-        tile_sync(nissue / 4);
+        // slab n+1 landed (only the pieces of slab n+2 may still fly); every wave done with slab n.
+        // SAVE: the activation stores issued during this slab (4 per tile that had a pending epilogue) are younger
+        // than every piece of slab n+1 as well, so they may stay in flight too
+        const int n_st = SAVE ? 4 * (s == 0 ? TPS - 1 : TPS) : 0;
+        tile_sync(nissue / 4 + n_st);
         p.ph = p.ph == RING - 1 ? 0 : p.ph + 1;
         p.bias_off += TPS * 128;
     }
@@ -380,8 +438,18 @@ __device__ __forceinline__ void layer16(Pipe& p, int nb1, int nb2, const h16x8 (
         for (int r = 0; r < 16; ++r) last[r] = pacc1[r] + pacc2[r] * LO_INV;
     } else {
 #pragma unroll
-        for (int i = 0; i < 8; ++i)
+        for (int i = 0; i < 8; ++i) {
+            if constexpr (SAVE) {
+                float x0, x1;
+                epi_pair_x<RELU>(pacc1, pacc2, i, oh[2 * (NT - 1) + (i >> 2)], ol[2 * (NT - 1) + (i >> 2)], x0, x1);
+                save_pair(*sc, bw, NT - 1, i, x0, x1);
+            } else
             epi_pair<RELU>(pacc1, pacc2, i, oh[2 * (NT - 1) + (i >> 2)], ol[2 * (NT - 1) + (i >> 2)]);
+        }
+        if constexpr (SAVE) {
+#pragma unroll
+            for (int i = 0; i < (NT + 1) / 2; ++i) sc->bits[i] = bw[i];
+        }
     }
 }
 
@@ -416,10 +484,15 @@ __device__ __forceinline__ void stash_pe(const Pipe& p, int ks, const float (&v)
 }
 
 // K3, f16x3.  grid = ceil(P / 128) workgroups of 4 waves x 32 samples; LDS = 160 KiB.
+// SAVE (training forward): also writes pe_out [P,63], acts [8][P][256] (fp32 post-ReLU values, as combined in the
+// epilogue) and relu_bits [8][P][8] like canonical_f32_kernel<true>; no sparse form.
+template <bool SAVE>
 __global__ __launch_bounds__(256) void canonical_f16x3_kernel(const float* __restrict__ xyz,
                                                               const char* __restrict__ packed, int64_t P,
                                                               float4* __restrict__ raw, const int* __restrict__ idx,
-                                                              const int* __restrict__ count) {
+                                                              const int* __restrict__ count,
+                                                              float* __restrict__ pe_out, float* __restrict__ acts,
+                                                              uint32_t* __restrict__ relu_bits) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // sparse launch: only the `*count` samples listed in idx are evaluated (hnrf_compact_samples)
     if (idx != nullptr) {
@@ -453,24 +526,41 @@ __global__ __launch_bounds__(256) void canonical_f16x3_kernel(const float* __res
                             pev[8 * ks + 4], pev[8 * ks + 5], pev[8 * ks + 6], pev[8 * ks + 7]};
         stash_pe(p, ks, v);
     }
+    SaveCtx sc;
+    if constexpr (SAVE) {
+        // lanes past P hold a copy of sample P-1 and (re)write its rows: same values, and every wave issues the
+        // same number of stores (see SaveCtx)
+        sc.row = acts + sidx * 256 + 4 * h;
+        sc.bits = relu_bits + sidx * 8 + 4 * h;
+#pragma unroll
+        for (int a = 0; a < 32; ++a) {
+            const int col = pe_col16(PE16_CANONICAL, a, h);
+            if (col >= 0) pe_out[sidx * 63 + col] = pev[a];
+        }
+    }
+    const int64_t act_stride = P * 256, bit_stride = P * 8;
     tile_sync(0);
 
     h16x8 hA_h[16], hA_l[16], hB_h[16], hB_l[16];
     float last[16];
-    layer16<8, 4, 4, 0, true>(p, CNL16_NB_MID, CNL16_NB_MID, hB_h, hB_l, hA_h, hA_l, last);   // (hB unused: NKB = 0)
+    layer16<8, 4, 4, 0, true, SAVE>(p, CNL16_NB_MID, CNL16_NB_MID, hB_h, hB_l, hA_h, hA_l, last, &sc);   // (hB unused: NKB = 0)
+    if constexpr (SAVE) { sc.row += act_stride; sc.bits += bit_stride; }
 #pragma unroll 1
     for (int l = 1; l <= 4; ++l) {
         const int nb = l == 4 ? CNL16_NB_L5 : CNL16_NB_MID;
-        layer16<8, 1, 0, 16, true>(p, nb, nb, hA_h, hA_l, hB_h, hB_l, last);
+        layer16<8, 1, 0, 16, true, SAVE>(p, nb, nb, hA_h, hA_l, hB_h, hB_l, last, &sc);
+        if constexpr (SAVE) { sc.row += act_stride; sc.bits += bit_stride; }
 #pragma unroll
         for (int i = 0; i < 16; ++i) { hA_h[i] = hB_h[i]; hA_l[i] = hB_l[i]; }
     }
-    layer16<8, 1, 4, 16, true>(p, CNL16_NB_MID, CNL16_NB_MID, hA_h, hA_l, hB_h, hB_l, last);   // skip layer
+    layer16<8, 1, 4, 16, true, SAVE>(p, CNL16_NB_MID, CNL16_NB_MID, hA_h, hA_l, hB_h, hB_l, last, &sc);   // skip layer
+    if constexpr (SAVE) { sc.row += act_stride; sc.bits += bit_stride; }
 #pragma unroll
     for (int i = 0; i < 16; ++i) { hA_h[i] = hB_h[i]; hA_l[i] = hB_l[i]; }
 #pragma unroll 1
     for (int l = 6; l <= 7; ++l) {
-        layer16<8, 1, 0, 16, true>(p, CNL16_NB_MID, l == 7 ? 0 : CNL16_NB_MID, hA_h, hA_l, hB_h, hB_l, last);
+        layer16<8, 1, 0, 16, true, SAVE>(p, CNL16_NB_MID, l == 7 ? 0 : CNL16_NB_MID, hA_h, hA_l, hB_h, hB_l, last, &sc);
+        if constexpr (SAVE) { sc.row += act_stride; sc.bits += bit_stride; }
 #pragma unroll
         for (int i = 0; i < 16; ++i) { hA_h[i] = hB_h[i]; hA_l[i] = hB_l[i]; }
     }
@@ -487,13 +577,16 @@ __global__ __launch_bounds__(256) void canonical_f16x3_kernel(const float* __res
 #endif
 }
 
-// K2, f16x3 (width 128: 4 tiles, 8 k-steps).
+// K2, f16x3 (width 128: 4 tiles, 8 k-steps).  SAVE: pe_out [P,36], acts [6][P][128], relu_bits [6][P][4].
+template <bool SAVE>
 __global__ __launch_bounds__(256) void nonrigid_f16x3_kernel(const float* __restrict__ x_skel,
                                                              const float* __restrict__ hann_w,
                                                              const char* __restrict__ packed, int64_t P,
                                                              float* __restrict__ xyz, float* __restrict__ offsets,
                                                              const int* __restrict__ idx,
-                                                             const int* __restrict__ count) {
+                                                             const int* __restrict__ count,
+                                                             float* __restrict__ pe_out, float* __restrict__ acts,
+                                                             uint32_t* __restrict__ relu_bits) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     if (idx != nullptr) {
         P = *count;
@@ -525,21 +618,32 @@ __global__ __launch_bounds__(256) void nonrigid_f16x3_kernel(const float* __rest
                             pev[8 * ks + 4], pev[8 * ks + 5], pev[8 * ks + 6], pev[8 * ks + 7]};
         stash_pe(p, ks, v);
     }
+    SaveCtx sc;
+    if constexpr (SAVE) {
+        sc.row = acts + sidx * 128 + 4 * h;
+        sc.bits = relu_bits + sidx * 4 + 2 * h;
+#pragma unroll
+        for (int a = 0; a < 18; ++a) pe_out[sidx * 36 + pe_col16(PE16_NONRIGID, a, h)] = pev[a];
+    }
+    const int64_t act_stride = P * 128, bit_stride = P * 4;
     tile_sync(0);
 
     h16x8 hA_h[8], hA_l[8], hB_h[8], hB_l[8];
     float last[16];
-    layer16<4, 4, 4, 0, true>(p, 0 /*already in flight*/, 2 * NR16_NB_MID, hB_h, hB_l, hA_h, hA_l, last);
+    layer16<4, 4, 4, 0, true, SAVE>(p, 0 /*already in flight*/, 2 * NR16_NB_MID, hB_h, hB_l, hA_h, hA_l, last, &sc);
+    if constexpr (SAVE) { sc.row += act_stride; sc.bits += bit_stride; }
 #pragma unroll 1
     for (int l = 1; l <= 3; ++l) {
         // 128-wide tiles have only 8 k-steps: two tiles per slab halve the barriers per MFMA
         const int nb = l == 3 ? NR16_NB_L4 : 2 * NR16_NB_MID;
-        layer16<4, 2, 0, 8, true>(p, nb, nb, hA_h, hA_l, hB_h, hB_l, last);
+        layer16<4, 2, 0, 8, true, SAVE>(p, nb, nb, hA_h, hA_l, hB_h, hB_l, last, &sc);
+        if constexpr (SAVE) { sc.row += act_stride; sc.bits += bit_stride; }
 #pragma unroll
         for (int i = 0; i < 8; ++i) { hA_h[i] = hB_h[i]; hA_l[i] = hB_l[i]; }
     }
-    layer16<4, 1, 4, 8, true>(p, 2 * NR16_NB_MID, 2 * NR16_NB_MID, hA_h, hA_l, hB_h, hB_l, last);    // skip layer
-    layer16<4, 2, 0, 8, true>(p, NR16_NB_MID, 0, hB_h, hB_l, hA_h, hA_l, last);
+    layer16<4, 1, 4, 8, true, SAVE>(p, 2 * NR16_NB_MID, 2 * NR16_NB_MID, hA_h, hA_l, hB_h, hB_l, last, &sc);    // skip layer
+    if constexpr (SAVE) { sc.row += act_stride; sc.bits += bit_stride; }
+    layer16<4, 2, 0, 8, true, SAVE>(p, NR16_NB_MID, 0, hB_h, hB_l, hA_h, hA_l, last, &sc);
     h16x8 dh[2], dl[2];
     layer16<1, 1, 0, 8, false>(p, 0, 0, hA_h, hA_l, dh, dl, last);
     const float* ob = reinterpret_cast<const float*>(packed + NR16_BIAS + NR16_BIAS_LDS);
@@ -618,16 +722,33 @@ int canonical16_fwd(const float* xyz, const void* packed, int64_t P, float* raw,
     constexpr int lds = CNL16_BIAS_LDS + PE_STASH + RING * CNL16_SLAB;
     static bool attr_set = false;
     if (!attr_set) {
-        if (hipFuncSetAttribute((const void*)canonical_f16x3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds) !=
-            hipSuccess) {
+        if (hipFuncSetAttribute((const void*)canonical_f16x3_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                lds) != hipSuccess) {
             set_error("hnrf_canonical_fwd (f16x3): cannot reserve %d bytes of LDS", lds);
             return HNRF_E_LAUNCH;
         }
         attr_set = true;
     }
-    hipLaunchKernelGGL(canonical_f16x3_kernel, dim3((unsigned)((P + 127) / 128)), dim3(256), lds, st, xyz,
-                       (const char*)packed, P, (float4*)raw, idx, count);
+    hipLaunchKernelGGL(canonical_f16x3_kernel<false>, dim3((unsigned)((P + 127) / 128)), dim3(256), lds, st, xyz,
+                       (const char*)packed, P, (float4*)raw, idx, count, nullptr, nullptr, nullptr);
     return check_launch("hnrf_canonical_fwd (f16x3)");
+}
+
+int canonical16_fwd_train(const float* xyz, const void* packed, int64_t P, float* raw, float* pe_out, float* acts,
+                          uint32_t* relu_bits, hipStream_t st) {
+    constexpr int lds = CNL16_BIAS_LDS + PE_STASH + RING * CNL16_SLAB;
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute((const void*)canonical_f16x3_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                lds) != hipSuccess) {
+            set_error("hnrf_canonical_fwd_train (f16x3): cannot reserve %d bytes of LDS", lds);
+            return HNRF_E_LAUNCH;
+        }
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(canonical_f16x3_kernel<true>, dim3((unsigned)((P + 127) / 128)), dim3(256), lds, st, xyz,
+                       (const char*)packed, P, (float4*)raw, nullptr, nullptr, pe_out, acts, relu_bits);
+    return check_launch("hnrf_canonical_fwd_train (f16x3)");
 }
 
 int nonrigid16_fwd(const float* x_skel, const float* hann_w, const void* packed, int64_t P, float* xyz,
@@ -635,16 +756,33 @@ int nonrigid16_fwd(const float* x_skel, const float* hann_w, const void* packed,
     constexpr int lds = NR16_BIAS_LDS + PE_STASH + RING * NR16_SLAB;
     static bool attr_set = false;
     if (!attr_set) {
-        if (hipFuncSetAttribute((const void*)nonrigid_f16x3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds) !=
-            hipSuccess) {
+        if (hipFuncSetAttribute((const void*)nonrigid_f16x3_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                lds) != hipSuccess) {
             set_error("hnrf_nonrigid_fwd (f16x3): cannot reserve %d bytes of LDS", lds);
             return HNRF_E_LAUNCH;
         }
         attr_set = true;
     }
-    hipLaunchKernelGGL(nonrigid_f16x3_kernel, dim3((unsigned)((P + 127) / 128)), dim3(256), lds, st, x_skel, hann_w,
-                       (const char*)packed, P, xyz, offsets, idx, count);
+    hipLaunchKernelGGL(nonrigid_f16x3_kernel<false>, dim3((unsigned)((P + 127) / 128)), dim3(256), lds, st, x_skel, hann_w,
+                       (const char*)packed, P, xyz, offsets, idx, count, nullptr, nullptr, nullptr);
     return check_launch("hnrf_nonrigid_fwd (f16x3)");
+}
+
+int nonrigid16_fwd_train(const float* x_skel, const float* hann_w, const void* packed, int64_t P, float* xyz,
+                         float* offsets, float* pe_out, float* acts, uint32_t* relu_bits, hipStream_t st) {
+    constexpr int lds = NR16_BIAS_LDS + PE_STASH + RING * NR16_SLAB;
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute((const void*)nonrigid_f16x3_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                lds) != hipSuccess) {
+            set_error("hnrf_nonrigid_fwd_train (f16x3): cannot reserve %d bytes of LDS", lds);
+            return HNRF_E_LAUNCH;
+        }
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(nonrigid_f16x3_kernel<true>, dim3((unsigned)((P + 127) / 128)), dim3(256), lds, st, x_skel, hann_w,
+                       (const char*)packed, P, xyz, offsets, nullptr, nullptr, pe_out, acts, relu_bits);
+    return check_launch("hnrf_nonrigid_fwd_train (f16x3)");
 }
 
 }  // namespace hnrf

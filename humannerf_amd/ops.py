@@ -187,9 +187,9 @@ def render_rays(rays_o, rays_d, near, far, t_rand, motion_Rs, motion_Ts, vol, bb
 
 
 # ----------------------------------------------------------------------------- training
-def canonical_train(xyz, packed):
+def canonical_train(xyz, packed, mode='f32'):
     """hnrf_canonical_fwd_train: raw (...,4), pe (P,63), acts (8,P,256), relu sign masks (8,P,8) int32.
-    fp32 mode only."""
+    ``packed`` must have been made for the same ``mode``."""
     lib = _lib.load()
     _chk(xyz, packed)
     P = xyz.numel() // 3
@@ -198,12 +198,12 @@ def canonical_train(xyz, packed):
     pe = torch.empty(P, 63, device=dev)
     acts = torch.empty(8, P, 256, device=dev)
     bits = torch.empty(8, P, 8, dtype=torch.int32, device=dev)
-    _lib.check(lib.hnrf_canonical_fwd_train(_ptr(xyz), _ptr(packed), MLP_MODES['f32'], P, _ptr(raw), _ptr(pe),
+    _lib.check(lib.hnrf_canonical_fwd_train(_ptr(xyz), _ptr(packed), MLP_MODES[mode], P, _ptr(raw), _ptr(pe),
                                             _ptr(acts), bits.data_ptr(), _stream()), 'hnrf_canonical_fwd_train')
     return raw, pe, acts, bits
 
 
-def nonrigid_train(x_skel, hann_w, packed):
+def nonrigid_train(x_skel, hann_w, packed, mode='f32'):
     """hnrf_nonrigid_fwd_train: xyz, offsets, pe (P,36), acts (6,P,128), relu sign masks (6,P,4) int32."""
     lib = _lib.load()
     _chk(x_skel, hann_w, packed)
@@ -213,7 +213,7 @@ def nonrigid_train(x_skel, hann_w, packed):
     pe = torch.empty(P, 36, device=dev)
     acts = torch.empty(6, P, 128, device=dev)
     bits = torch.empty(6, P, 4, dtype=torch.int32, device=dev)
-    _lib.check(lib.hnrf_nonrigid_fwd_train(_ptr(x_skel), _ptr(hann_w), _ptr(packed), MLP_MODES['f32'], P, _ptr(xyz),
+    _lib.check(lib.hnrf_nonrigid_fwd_train(_ptr(x_skel), _ptr(hann_w), _ptr(packed), MLP_MODES[mode], P, _ptr(xyz),
                                            _ptr(offsets), _ptr(pe), _ptr(acts), bits.data_ptr(), _stream()),
                'hnrf_nonrigid_fwd_train')
     return xyz, offsets, pe, acts, bits

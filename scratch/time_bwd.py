@@ -25,3 +25,6 @@ def t(fn, n=5):
 print('canonical fwd (infer) %.3f ms' % t(lambda: ops.canonical(x, cp, 'f32')))
 print('canonical fwd (train) %.3f ms' % t(lambda: ops.canonical_train(x, cp)))
 print('canonical bwd chain   %.3f ms' % t(lambda: ops.canonical_bwd(x, g, bits, cw)))
+cp16 = ops.canonical_pack(cw, cb, 'f16x3')
+print('canonical fwd f16x3 (infer) %.3f ms' % t(lambda: ops.canonical(x, cp16, 'f16x3')))
+print('canonical fwd f16x3 (train) %.3f ms' % t(lambda: ops.canonical_train(x, cp16, 'f16x3')))

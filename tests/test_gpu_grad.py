@@ -132,7 +132,8 @@ def test_pe_bwd_kernel():
         assert err <= 1e-4, float(err)
 
 
-def test_training_forward_equals_inference_forward():
+@pytest.mark.parametrize('mode', ['f32', 'f16x3'])
+def test_training_forward_equals_inference_forward(mode):
     """The activation-saving forward returns the same raw values as the inference kernel, and the
     saved activations are what the oracle computes."""
     from humannerf_amd import ops
@@ -146,9 +147,9 @@ def test_training_forward_equals_inference_forward():
     T = lambda a: torch.from_numpy(a).to(dev())
     ws = [T(st[f'cnl_mlp.module.pts_linears.{i}.weight']) for i in idx] + [T(st['cnl_mlp.module.output_linear.0.weight'])]
     bs = [T(st[f'cnl_mlp.module.pts_linears.{i}.bias']) for i in idx] + [T(st['cnl_mlp.module.output_linear.0.bias'])]
-    packed = ops.canonical_pack(ws, bs, 'f32')
-    raw = ops.canonical(T(xyz), packed, 'f32')
-    raw_t, pe, acts, bits = ops.canonical_train(T(xyz), packed)
+    packed = ops.canonical_pack(ws, bs, mode)
+    raw = ops.canonical(T(xyz), packed, mode)
+    raw_t, pe, acts, bits = ops.canonical_train(T(xyz), packed, mode)
     assert bits.shape == (8, P, 8)
     assert torch.equal(raw, raw_t)
     pe_ref = oracle.fourier_pe(torch.from_numpy(xyz), 10)
@@ -156,6 +157,16 @@ def test_training_forward_equals_inference_forward():
     h = torch.relu(torch.nn.functional.linear(pe_ref, torch.from_numpy(st['cnl_mlp.module.pts_linears.0.weight']),
                                               torch.from_numpy(st['cnl_mlp.module.pts_linears.0.bias'])))
     assert (acts[0].cpu() - h).abs().max() <= 1e-5
+    # every layer's saved activations against an fp64 evaluation of the same MLP
+    names = [f'cnl_mlp.module.pts_linears.{i}' for i in idx]
+    pe64 = pe_ref.double()
+    h64 = pe64
+    for l, n in enumerate(names):
+        if l == 5:
+            h64 = torch.cat([pe64, h64], -1)
+        h64 = torch.relu(torch.nn.functional.linear(h64, torch.from_numpy(st[n + '.weight']).double(),
+                                                    torch.from_numpy(st[n + '.bias']).double()))
+        assert (acts[l].double().cpu() - h64).abs().max() <= 2e-5 * max(1.0, float(h64.abs().max())), l
 
 
 def _torch_mlp(x_in, ws, bs, skip_layer, skip_order, pe_fn, masks):
@@ -171,7 +182,8 @@ def _torch_mlp(x_in, ws, bs, skip_layer, skip_order, pe_fn, masks):
     return torch.nn.functional.linear(h, ws[-1], bs[-1])
 
 
-def test_canonical_backward_chain_and_weight_gradients_match_autograd():
+@pytest.mark.parametrize('mode', ['f32', 'f16x3'])
+def test_canonical_backward_chain_and_weight_gradients_match_autograd(mode):
     """hnrf_canonical_bwd (dX chain + fused PE') and hnrf_mlp_dw against torch.autograd of the same MLP
     (fp64 on the CPU): dZ of every layer, d_xyz, and every dW / db."""
     from humannerf_amd import ops
@@ -187,7 +199,7 @@ def test_canonical_backward_chain_and_weight_gradients_match_autograd():
     names = [f'cnl_mlp.module.pts_linears.{i}' for i in idx] + ['cnl_mlp.module.output_linear.0']
     T = lambda a: torch.from_numpy(a).to(dev())
     ws, bs = [T(st[n + '.weight']) for n in names], [T(st[n + '.bias']) for n in names]
-    raw, pe, acts, bits = ops.canonical_train(T(xyz), ops.canonical_pack(ws, bs, 'f32'))
+    raw, pe, acts, bits = ops.canonical_train(T(xyz), ops.canonical_pack(ws, bs, mode), mode)
     dZ, d_xyz = ops.canonical_bwd(T(xyz), T(g_raw), bits, ws)
     gW, gb = _weight_grads(dZ, acts, pe, T(g_raw), ws, skip_layer=5, skip_order='pe_first')
 
@@ -204,7 +216,8 @@ def test_canonical_backward_chain_and_weight_gradients_match_autograd():
         assert rel(gb[l], b64[l].grad) <= 2e-5, l
 
 
-def test_nonrigid_backward_chain_and_weight_gradients_match_autograd():
+@pytest.mark.parametrize('mode', ['f32', 'f16x3'])
+def test_nonrigid_backward_chain_and_weight_gradients_match_autograd(mode):
     """hnrf_nonrigid_bwd + hnrf_mlp_dw against torch.autograd (fp64): d_x_skel includes the identity path of
     xyz = x_skel + offset, the Hann window weights scale the PE gradient, the condition code enters layer 0."""
     from humannerf_amd import ops
@@ -221,7 +234,7 @@ def test_nonrigid_backward_chain_and_weight_gradients_match_autograd():
     names = [f'non_rigid_mlp.module.block_mlps.{i}' for i in (0, 2, 4, 6, 8, 10, 12)]
     T = lambda a: torch.from_numpy(a).to(dev())
     ws, bs = [T(st[n + '.weight']) for n in names], [T(st[n + '.bias']) for n in names]
-    xyz, off, pe, acts, bits = ops.nonrigid_train(T(x), T(hann), ops.nonrigid_pack(ws, bs, T(cond), 'f32'))
+    xyz, off, pe, acts, bits = ops.nonrigid_train(T(x), T(hann), ops.nonrigid_pack(ws, bs, T(cond), mode), mode)
     dZ, d_x = ops.nonrigid_bwd(T(x), T(hann), T(g_xyz), bits, ws)
     gW, gb = _weight_grads(dZ, acts, pe, T(g_xyz), ws, skip_layer=4, skip_order='h_first')
     gW[0] = torch.cat([gb[0][:, None] * T(cond).reshape(1, -1), gW[0]], dim=1)
