@@ -14,12 +14,16 @@ from . import ops
 from .config import amd_option
 
 
-def _weight_grads(dZ, acts, pe, dY, weights, skip_layer, skip_order):
+def _weight_grads(dZ, acts, pe, dY, weights, skip_layer, skip_order, amax=None, mode='f32'):
     """dW / db of every layer from the chain kernel's dZ [L][P][W], the saved activations and PE matrix.
-    dY: gradient at the (3- / 4-wide) head output."""
+    dY: gradient at the (3- / 4-wide) head output.  mode 'f16x3' (with amax from the chain kernel) runs the
+    matrix-shaped layers on the split-f16 kernel; PE blocks and heads stay fp32."""
     n_hidden = acts.shape[0]
     npe = pe.shape[1]
     gW, gb = [None] * (n_hidden + 1), [None] * (n_hidden + 1)
+    am = (lambda l: amax[l]) if amax is not None else (lambda l: None)
+    if amax is None:
+        mode = 'f32'
     gW[n_hidden], gb[n_hidden] = ops.mlp_dw(dY, acts[n_hidden - 1])
     for l in range(n_hidden):
         if l == 0:
@@ -29,9 +33,9 @@ def _weight_grads(dZ, acts, pe, dY, weights, skip_layer, skip_order):
             pe_cols = gW[l][:, :npe] if skip_order == 'pe_first' else gW[l][:, -npe:]
             h_cols = gW[l][:, npe:] if skip_order == 'pe_first' else gW[l][:, :-npe]
             ops.mlp_dw(dZ[l], pe, pe_cols, want_db=False)
-            _, gb[l] = ops.mlp_dw(dZ[l], acts[l - 1], h_cols)
+            _, gb[l] = ops.mlp_dw(dZ[l], acts[l - 1], h_cols, mode=mode, dz_amax=am(l))
         else:
-            gW[l], gb[l] = ops.mlp_dw(dZ[l], acts[l - 1])
+            gW[l], gb[l] = ops.mlp_dw(dZ[l], acts[l - 1], mode=mode, dz_amax=am(l))
     return gW, gb
 
 
@@ -71,13 +75,16 @@ class RenderRays(torch.autograd.Function):
         d_raw, d_mask = ops.composite_bwd(raw, mask, z, rays_d, bg, c(g_rgb), c(g_alpha), c(g_depth))
         # canonical MLP (skip layer 5 takes [PE63 | h]): dX chain with the PE backward fused, then the weight gradients
         d_raw = d_raw.view(P, 4)
-        dZc, d_xyz = ops.canonical_bwd(xyz.reshape(P, 3), d_raw, bits_c, cn_w)
-        gWc, gbc = _weight_grads(dZc, acts_c, pe_c, d_raw, cn_w, skip_layer=5, skip_order='pe_first')
+        dw_mode = amd_option('train_dw_mode', 'f16x3')
+        dZc, d_xyz, amax_c = ops.canonical_bwd(xyz.reshape(P, 3), d_raw, bits_c, cn_w)
+        gWc, gbc = _weight_grads(dZc, acts_c, pe_c, d_raw, cn_w, skip_layer=5, skip_order='pe_first', amax=amax_c,
+                                 mode=dw_mode)
         del dZc
         if ctx.use_nonrigid:
             # xyz = x_skel + offset; layer 0 input [cond69 | PE36], skip layer 4 takes [h | PE36]
-            dZn, d_x_skel = ops.nonrigid_bwd(x_skel.reshape(P, 3), hann_w, d_xyz, bits_n, nr_w)
-            gWn, gbn = _weight_grads(dZn, acts_n, pe_n, d_xyz, nr_w, skip_layer=4, skip_order='h_first')
+            dZn, d_x_skel, amax_n = ops.nonrigid_bwd(x_skel.reshape(P, 3), hann_w, d_xyz, bits_n, nr_w)
+            gWn, gbn = _weight_grads(dZn, acts_n, pe_n, d_xyz, nr_w, skip_layer=4, skip_order='h_first', amax=amax_n,
+                                     mode=dw_mode)
             # condition-code columns of layer 0: the same vector for every sample
             gWn[0] = torch.cat([gbn[0][:, None] * cond.reshape(1, -1), gWn[0]], dim=1)
         else:

@@ -120,6 +120,8 @@ _DEFAULTS = {
         'mlp_mode': 'f16x3',
         # arithmetic of the activation-saving training forward (the backward kernels are fp32 MFMA either way)
         'train_mlp_mode': 'f16x3',
+        # arithmetic of the weight-gradient kernel for the matrix-shaped layers ('f32' | 'f16x3')
+        'train_dw_mode': 'f16x3',
         # materialise the per-sample diagnostic outputs the reference always
         # returns (backward_motion_weights, xyz_on_rays, ...; ~17 KB/ray).
         'diagnostics': True,

@@ -142,6 +142,186 @@ __global__ __launch_bounds__(256) void mlp_dw_kernel(const float* __restrict__ d
     }
 }
 
+// ---------------------------------------------------------------------------- dW, split-f16
+// Same decomposition (one workgroup per CU owns the whole output, samples streamed once), but the products run
+// on the f16 matrix pipe at fp32-class accuracy: every operand v is split hi = f16(v), lo = f16(v - hi) and
+//   a b ~= ah bh + ah bl + al bh      (three v_mfma_f32_32x32x16_f16 into ONE fp32 accumulator).
+// What matters for a sum over ~10^6 samples is the ABSOLUTE error of each operand: dZ is scaled by a power of
+// two so that its largest magnitude lands in [2^7, 2^8) (amax comes from the chain kernel), which puts the
+// residual lo in f16's normal range for every element that matters and bounds the operand error by
+// max(2^-22 |v|, 2^-25 * 2^-8 amax); X (activations, |x| <= 65504 by the forward's clamp) needs no scale.
+// The MFMA wants 8 consecutive SAMPLES of one column per lane, the matrices are [sample][column]: the wave's own
+// dZ columns are gathered by 8 row loads per lane (two columns each, tile interleave as above); X is shared by
+// the 4 waves, so each thread converts 1/256 of the 16 x 256 block of a k-step and the fragments meet in LDS
+// (double-buffered, one raw s_barrier per k-step -- __syncthreads() would drain the global prefetch ring).
+// Per k-step (16 samples) a wave issues 48 MFMAs (1536 cycles) against 12 loads and ~100 VALU: matrix-bound,
+// and at 0.3-0.4 ms per 256x256 layer it runs into the 1.6 GB / layer of HBM reads.
+typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2v __attribute__((ext_vector_type(2)));
+
+constexpr int DW16_DEPTH = 4;      // k-steps of raw global loads in flight (also the unroll of the main loop)
+
+__device__ __forceinline__ void split_pair(float v0, float v1, _Float16& h0, _Float16& h1, _Float16& l0, _Float16& l1) {
+    const f32x2v p = {__builtin_amdgcn_fmed3f(v0, -65504.f, 65504.f), __builtin_amdgcn_fmed3f(v1, -65504.f, 65504.f)};
+    const h16x2 hh = __builtin_convertvector(p, h16x2);
+    const f32x2v r = p - __builtin_convertvector(hh, f32x2v);
+    const h16x2 ll = __builtin_convertvector(r, h16x2);
+    h0 = hh[0]; h1 = hh[1]; l0 = ll[0]; l1 = ll[1];
+}
+
+__device__ __forceinline__ void lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+// OT: 32-row tiles of dZ columns per wave (n_out = 128 OT); IB: 128-column blocks of X (n_in = 128 IB).
+template <int OT, int IB>
+__global__ __launch_bounds__(256) void mlp_dw16_kernel(const float* __restrict__ dZ, int64_t ldz,
+                                                       const float* __restrict__ X, int64_t ldx, int64_t P,
+                                                       int64_t per_wg, const float* __restrict__ dz_amax,
+                                                       int n_amax, float* __restrict__ part,
+                                                       float* __restrict__ dbpart) {
+    constexpr int IT = 4 * IB, NOW = 128 * OT, NIP = 32 * IT;
+    constexpr int RPT = 2 * IB;                  // X rows per thread and k-step (256 threads cover 16 x 128 IB)
+    constexpr int NQ = 32 * IB;                  // column quads
+    __shared__ h16x8 bfrag[2][IT * 2 * 64];      // [buffer][(tile, hi|lo)][lane]
+    const int tid = threadIdx.x, lane = tid & 63, c = lane & 31, h = lane >> 5, w = tid >> 6;
+    const int64_t s0 = (int64_t)blockIdx.x * per_wg;
+    const int64_t s1 = s0 + per_wg < P ? s0 + per_wg : P;
+    // power-of-two scale of dZ: largest magnitude -> [2^7, 2^8)
+    int ex = 0;
+    float amax = 0.f;
+    for (int i = 0; i < n_amax; ++i) amax = fmaxf(amax, dz_amax[i]);   // uniform address: scalar loads
+    if (amax > 0.f) (void)frexpf(amax, &ex);
+    const float scale = ldexpf(1.0f, 8 - ex), descale = ldexpf(1.0f, ex - 8);
+
+    f32x16 acc[OT][IT];
+#pragma unroll
+    for (int a = 0; a < OT; ++a)
+#pragma unroll
+        for (int b = 0; b < IT; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+    float bsum[OT];
+#pragma unroll
+    for (int a = 0; a < OT; ++a) bsum[a] = 0.f;
+
+    // this thread's share of X: column quad `quad`, rows RPT*part .. of each 16-row k-step
+    const int quad = tid % NQ, part_i = tid / NQ;
+    const int xr0 = RPT * part_i;
+    const float* ap = dZ + 32 * OT * w + OT * c;
+    const float* bp = X + 4 * quad;
+    // LDS destination of the thread's half-fragments: tile 4 (quad >> 5) + q, lane (xr0 >> 3) * 32 + (quad & 31)
+    const int frag_lane = (xr0 >> 3) * 32 + (quad & 31);
+
+    float araw[DW16_DEPTH][8][OT];
+    float braw[DW16_DEPTH][RPT][4];
+    auto fetch = [&](int slot, int64_t ks) {
+        const int64_t sa = s0 + 16 * ks + 8 * h;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int64_t s = sa + j < s1 ? sa + j : s1 - 1;
+            if (OT == 2) {
+                const f32x2p v = *reinterpret_cast<const f32x2p*>(ap + s * ldz);
+                araw[slot][j][0] = v.x;
+                araw[slot][j][OT - 1] = v.y;
+            } else {
+                araw[slot][j][0] = ap[s * ldz];
+            }
+        }
+        const int64_t sb = s0 + 16 * ks + xr0;
+#pragma unroll
+        for (int r = 0; r < RPT; ++r) {
+            const int64_t s = sb + r < s1 ? sb + r : s1 - 1;
+            const f32x4v v = *reinterpret_cast<const f32x4v*>(bp + s * ldx);
+            braw[slot][r][0] = v.x; braw[slot][r][1] = v.y; braw[slot][r][2] = v.z; braw[slot][r][3] = v.w;
+        }
+    };
+    // X rows of k-step ks (ring slot) -> f16 hi / lo half-fragments in LDS buffer buf
+    auto stage_b = [&](int slot, int buf) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            _Float16 hi[RPT], lo[RPT];
+#pragma unroll
+            for (int r = 0; r < RPT; r += 2) split_pair(braw[slot][r][q], braw[slot][r + 1][q], hi[r], hi[r + 1], lo[r], lo[r + 1]);
+            const int tile = 4 * (quad >> 5) + q;
+            typedef _Float16 hvec __attribute__((ext_vector_type(RPT)));
+            hvec vh, vl;
+#pragma unroll
+            for (int r = 0; r < RPT; ++r) { vh[r] = hi[r]; vl[r] = lo[r]; }
+            *reinterpret_cast<hvec*>(reinterpret_cast<_Float16*>(&bfrag[buf][(tile * 2 + 0) * 64 + frag_lane]) + (xr0 & 7)) = vh;
+            *reinterpret_cast<hvec*>(reinterpret_cast<_Float16*>(&bfrag[buf][(tile * 2 + 1) * 64 + frag_lane]) + (xr0 & 7)) = vl;
+        }
+    };
+
+    const int64_t nks = per_wg / 16;                           // per_wg is a multiple of 16 DW16_DEPTH
+#pragma unroll
+    for (int d = 0; d < DW16_DEPTH; ++d) fetch(d, d);
+    stage_b(0, 0);
+    lds_barrier();
+    for (int64_t k0 = 0; k0 < nks; k0 += DW16_DEPTH) {
+#pragma unroll
+        for (int d = 0; d < DW16_DEPTH; ++d) {
+            // this wave's dZ columns of k-step k0 + d: scale, zero the rows past the slice, split
+            h16x8 ah[OT], al[OT];
+#pragma unroll
+            for (int q = 0; q < OT; ++q) {
+                float v[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const bool ok = s0 + 16 * (k0 + d) + 8 * h + j < s1;
+                    v[j] = ok ? araw[d][j][q] : 0.f;
+                    bsum[q] += v[j];
+                    v[j] *= scale;
+                }
+#pragma unroll
+                for (int j = 0; j < 8; j += 2) {
+                    _Float16 h0, h1, l0, l1;
+                    split_pair(v[j], v[j + 1], h0, h1, l0, l1);
+                    ah[q][j] = h0; ah[q][j + 1] = h1; al[q][j] = l0; al[q][j + 1] = l1;
+                }
+            }
+            stage_b((d + 1) % DW16_DEPTH, (d + 1) & 1);        // X of the NEXT k-step -> the other LDS buffer
+            fetch(d, k0 + d + DW16_DEPTH);                      // refill this ring slot
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int it = 0; it < IT; ++it) {
+                const h16x8 bh = bfrag[d & 1][(it * 2 + 0) * 64 + lane];
+                const h16x8 bl = bfrag[d & 1][(it * 2 + 1) * 64 + lane];
+#pragma unroll
+                for (int qa = 0; qa < OT; ++qa) acc[qa][it] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[qa], bh, acc[qa][it], 0, 0, 0);
+#pragma unroll
+                for (int qa = 0; qa < OT; ++qa) acc[qa][it] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[qa], bl, acc[qa][it], 0, 0, 0);
+#pragma unroll
+                for (int qa = 0; qa < OT; ++qa) acc[qa][it] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[qa], bh, acc[qa][it], 0, 0, 0);
+            }
+            lds_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+
+    float* out = part + (int64_t)blockIdx.x * NOW * NIP;
+#pragma unroll
+    for (int qa = 0; qa < OT; ++qa)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int ra = (r & 3) + 8 * (r >> 2) + 4 * h;
+            float* row = out + (int64_t)(32 * OT * w + OT * ra + qa) * NIP;
+#pragma unroll
+            for (int b = 0; b < IB; ++b)
+                *reinterpret_cast<f32x4v*>(row + 128 * b + 4 * c) =
+                    f32x4v{acc[qa][4 * b][r] * descale, acc[qa][4 * b + 1][r] * descale, acc[qa][4 * b + 2][r] * descale,
+                           acc[qa][4 * b + 3][r] * descale};
+        }
+    if (dbpart != nullptr) {
+#pragma unroll
+        for (int qa = 0; qa < OT; ++qa) {
+            const float t = bsum[qa] + __shfl_xor(bsum[qa], 32, 64);
+            if (h == 0) dbpart[(int64_t)blockIdx.x * NOW + 32 * OT * w + OT * c + qa] = t;
+        }
+    }
+}
+
 // Head layers (n_out <= 4: sigma/rgb, xyz offset): no matrix work, one pass over X.  Thread i owns column i of
 // its slice; dY rows arrive through the scalar cache.  Partials in the layout of mlp_dw_kernel (NOW = 4).
 template <int NI>
@@ -224,12 +404,12 @@ struct DwPlan {
     int nsplit;
 };
 
-static bool dw_plan(int64_t P, int n_out, int n_in, DwPlan& pl) {
+static bool dw_plan(int64_t P, int n_out, int n_in, DwPlan& pl, bool f16 = false) {
     if (n_out == 256 || n_out == 128) pl.now = n_out; else if (n_out >= 1 && n_out <= 4) pl.now = 4; else return false;
     if (n_in == 256 || n_in == 128) pl.nip = n_in;
     else if (n_in >= 1 && n_in <= 64 && n_out > 4) pl.nip = 64;
     else return false;
-    const int64_t unit = 2 * DW_DEPTH;
+    const int64_t unit = f16 ? 16 * DW16_DEPTH : 2 * DW_DEPTH;
     int64_t per = (P + DW_SPLIT - 1) / DW_SPLIT;
     per = (per + unit - 1) / unit * unit;
     if (per < 4 * unit) per = 4 * unit;
@@ -251,6 +431,8 @@ static bool dw_plan(int64_t P, int n_out, int n_in, DwPlan& pl) {
 // sample: the PE backward is fused (d_xyz leaves the kernel, d PE never exists in memory).
 // Every dZ_l is written once ([L][P][width], the layout of the saved activations) for
 // hnrf_mlp_dw.  Per sample: 8 KB of activations read + 8 KB of dZ written (canonical).
+
+// HNRF_AMAX_SLOTS (hnrf.h): per-layer |dZ| maxima are spread over this many atomic targets
 
 struct PackBwd {
     const float* W;        // nn.Linear weight (n_out, n_in) of the forward layer
@@ -299,11 +481,12 @@ __global__ void pack_bwd_kernel(PackBwd d, float* __restrict__ packed) {
 template <int PH, int NT, int NG, int NB, int NO>
 __device__ __forceinline__ void bwd_stage(const float4* __restrict__& wptr, float4 (&ring)[PF], const float (&b)[NB],
                                           float (&out)[NO], const uint32_t* __restrict__ mbits,
-                                          float* __restrict__ dz, int h) {
+                                          float* __restrict__ dz, int h, float* __restrict__ amax_slot = nullptr) {
     static_assert(NB >= NG * 4 && NO >= NT * 16, "operand arrays too small");
     uint32_t mw[(NT + 1) / 2];
 #pragma unroll
     for (int i = 0; i < (NT + 1) / 2; ++i) mw[i] = mbits != nullptr ? mbits[i] : 0xffffffffu;
+    float stage_max = 0.f;                       // largest |dZ| of this stage (scale of the split-f16 dW kernel)
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
         f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -324,6 +507,10 @@ __device__ __forceinline__ void bwd_stage(const float4* __restrict__& wptr, floa
         const uint32_t m = mw[t >> 1] >> (16 * (t & 1));
 #pragma unroll
         for (int r = 0; r < 16; ++r) out[t * 16 + r] = (m >> r) & 1u ? acc[r] : 0.f;
+        if (amax_slot != nullptr) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) stage_max = fmaxf(stage_max, fabsf(out[t * 16 + r]));
+        }
         if (dz != nullptr) {
 #pragma unroll
             for (int q = 0; q < 4; ++q)
@@ -331,6 +518,11 @@ __device__ __forceinline__ void bwd_stage(const float4* __restrict__& wptr, floa
                     make_float4(out[t * 16 + 4 * q], out[t * 16 + 4 * q + 1], out[t * 16 + 4 * q + 2],
                                 out[t * 16 + 4 * q + 3]);
         }
+    }
+    if (amax_slot != nullptr) {                  // one atomic per wave and layer, spread over 64 slots per layer
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) stage_max = fmaxf(stage_max, __shfl_xor(stage_max, off, 64));
+        if ((threadIdx.x & 63) == 0) atomicMax(reinterpret_cast<unsigned int*>(amax_slot), __float_as_uint(stage_max));
     }
 }
 
@@ -365,10 +557,13 @@ __global__ __launch_bounds__(256) void canonical_bwd_kernel(const float* __restr
                                                             const float4* __restrict__ d_raw,
                                                             const uint32_t* __restrict__ relu_bits,
                                                             const float* __restrict__ packed, int64_t P,
-                                                            float* __restrict__ dZ, float* __restrict__ d_xyz) {
+                                                            float* __restrict__ dZ, float* __restrict__ d_xyz,
+                                                            float* __restrict__ dz_amax) {
     const int lane = threadIdx.x & 63, h = lane >> 5;
     const int64_t slot = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 32 + (lane & 31);
     const int64_t sample = slot < P ? slot : P - 1;            // clamped lanes compute, but never store
+    // dz_amax [8][HNRF_AMAX_SLOTS]: clamped lanes repeat sample P-1, which cannot raise a maximum
+    float* am = dz_amax ? dz_amax + 7 * HNRF_AMAX_SLOTS + (blockIdx.x % HNRF_AMAX_SLOTS) : nullptr;
     const bool live = slot < P;
     const int64_t stride = P * 256;
 
@@ -384,18 +579,20 @@ __global__ __launch_bounds__(256) void canonical_bwd_kernel(const float* __restr
     float hA[128], hB[128], dpe[32], dpe0[32];
     constexpr int C_PH = 8 % PF;                               // after the 8-group head every stage is a multiple of 64 groups
     static_assert(64 % PF == 0, "stages must keep the ring phase");
-    bwd_stage<0, 8, 1>(wptr, ring, in0, hA, act, live ? dz : nullptr, h);                  // dZ7
+    bwd_stage<0, 8, 1>(wptr, ring, in0, hA, act, live ? dz : nullptr, h, am);                  // dZ7
 #pragma unroll 1
     for (int l = 7; l >= 6; --l) {                                                      // dZ6, dZ5
         act -= bstride;
         dz -= stride;
-        bwd_stage<C_PH, 8, 32>(wptr, ring, hA, hB, act, live ? dz : nullptr, h);
+        if (am) am -= HNRF_AMAX_SLOTS;
+        bwd_stage<C_PH, 8, 32>(wptr, ring, hA, hB, act, live ? dz : nullptr, h, am);
 #pragma unroll
         for (int i = 0; i < 128; ++i) hA[i] = hB[i];
     }
     act -= bstride;
     dz -= stride;
-    bwd_stage<C_PH, 8, 32>(wptr, ring, hA, hB, act, live ? dz : nullptr, h);                  // skip layer: dZ4 ...
+    if (am) am -= HNRF_AMAX_SLOTS;
+    bwd_stage<C_PH, 8, 32>(wptr, ring, hA, hB, act, live ? dz : nullptr, h, am);                  // skip layer: dZ4 ...
     bwd_stage<C_PH, 2, 32>(wptr, ring, hA, dpe, nullptr, nullptr, h);                         // ... and its d PE
 #pragma unroll
     for (int i = 0; i < 128; ++i) hA[i] = hB[i];
@@ -403,7 +600,8 @@ __global__ __launch_bounds__(256) void canonical_bwd_kernel(const float* __restr
     for (int l = 4; l >= 1; --l) {                                                      // dZ3 .. dZ0
         act -= bstride;
         dz -= stride;
-        bwd_stage<C_PH, 8, 32>(wptr, ring, hA, hB, act, live ? dz : nullptr, h);
+        if (am) am -= HNRF_AMAX_SLOTS;
+        bwd_stage<C_PH, 8, 32>(wptr, ring, hA, hB, act, live ? dz : nullptr, h, am);
 #pragma unroll
         for (int i = 0; i < 128; ++i) hA[i] = hB[i];
     }
@@ -442,10 +640,12 @@ __global__ __launch_bounds__(256) void nonrigid_bwd_kernel(const float* __restri
                                                            const float* __restrict__ d_xyz,
                                                            const uint32_t* __restrict__ relu_bits,
                                                            const float* __restrict__ packed, int64_t P,
-                                                           float* __restrict__ dZ, float* __restrict__ d_x_skel) {
+                                                           float* __restrict__ dZ, float* __restrict__ d_x_skel,
+                                                           float* __restrict__ dz_amax) {
     const int lane = threadIdx.x & 63, h = lane >> 5;
     const int64_t slot = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 32 + (lane & 31);
     const int64_t sample = slot < P ? slot : P - 1;
+    float* am = dz_amax ? dz_amax + 5 * HNRF_AMAX_SLOTS + (blockIdx.x % HNRF_AMAX_SLOTS) : nullptr;
     const bool live = slot < P;
     const int64_t stride = P * 128;
 
@@ -461,19 +661,22 @@ __global__ __launch_bounds__(256) void nonrigid_bwd_kernel(const float* __restri
     float hA[64], hB[64], dpe[32], dpe0[32];
     constexpr int N_PH = 4 % PF;                               // 4-group head, then multiples of 32 groups
     static_assert(32 % PF == 0, "stages must keep the ring phase");
-    bwd_stage<0, 4, 1>(wptr, ring, in0, hA, act, live ? dz : nullptr, h);                  // dZ5
+    bwd_stage<0, 4, 1>(wptr, ring, in0, hA, act, live ? dz : nullptr, h, am);                  // dZ5
     act -= bstride;
     dz -= stride;
-    bwd_stage<N_PH, 4, 16>(wptr, ring, hA, hB, act, live ? dz : nullptr, h);                  // dZ4 (the skip layer's)
+    if (am) am -= HNRF_AMAX_SLOTS;
+    bwd_stage<N_PH, 4, 16>(wptr, ring, hA, hB, act, live ? dz : nullptr, h, am);                  // dZ4 (the skip layer's)
     act -= bstride;
     dz -= stride;
-    bwd_stage<N_PH, 4, 16>(wptr, ring, hB, hA, act, live ? dz : nullptr, h);                  // skip [h | PE]: dZ3 ...
+    if (am) am -= HNRF_AMAX_SLOTS;
+    bwd_stage<N_PH, 4, 16>(wptr, ring, hB, hA, act, live ? dz : nullptr, h, am);                  // skip [h | PE]: dZ3 ...
     bwd_stage<N_PH, 2, 16>(wptr, ring, hB, dpe, nullptr, nullptr, h);                         // ... and its d PE
 #pragma unroll 1
     for (int l = 3; l >= 1; --l) {                                                      // dZ2 .. dZ0
         act -= bstride;
         dz -= stride;
-        bwd_stage<N_PH, 4, 16>(wptr, ring, hA, hB, act, live ? dz : nullptr, h);
+        if (am) am -= HNRF_AMAX_SLOTS;
+        bwd_stage<N_PH, 4, 16>(wptr, ring, hA, hB, act, live ? dz : nullptr, h, am);
 #pragma unroll
         for (int i = 0; i < 64; ++i) hA[i] = hB[i];
     }
@@ -519,16 +722,22 @@ extern "C" size_t hnrf_mlp_dw_workspace_bytes(int64_t P, int n_out, int n_in) {
 }
 
 extern "C" int hnrf_mlp_dw(const float* dZ, int64_t ldz, const float* X, int64_t ldx, int64_t P, int n_out, int n_in,
-                           float* dW, int64_t ldw, float* db, void* workspace, size_t workspace_bytes, void* stream) {
+                           int mode, const float* dz_amax, int n_amax, float* dW, int64_t ldw, float* db,
+                           void* workspace, size_t workspace_bytes, void* stream) {
     HNRF_REQUIRE(dZ && X && dW && workspace, HNRF_E_ARG, "hnrf_mlp_dw: null pointer");
+    HNRF_REQUIRE(mode == HNRF_MLP_F32 || mode == HNRF_MLP_F16X3, HNRF_E_UNSUPPORTED, "hnrf_mlp_dw: mode %d not built", mode);
+    // split-f16 is built for the matrix-shaped layers; positional-encoding blocks and heads stay on the fp32 kernels
+    const bool f16 = mode == HNRF_MLP_F16X3 && (n_out == 128 || n_out == 256) && (n_in == 128 || n_in == 256);
+    HNRF_REQUIRE(!f16 || (dz_amax && n_amax >= 1 && n_amax <= 4096), HNRF_E_ARG,
+                 "hnrf_mlp_dw: HNRF_MLP_F16X3 needs dz_amax (n_amax device floats whose maximum bounds |dZ|)");
     DwPlan pl;
-    HNRF_REQUIRE(P > 0 && dw_plan(P, n_out, n_in, pl), HNRF_E_UNSUPPORTED,
+    HNRF_REQUIRE(P > 0 && dw_plan(P, n_out, n_in, pl, f16), HNRF_E_UNSUPPORTED,
                  "hnrf_mlp_dw: shape P=%lld n_out=%d n_in=%d not built (n_out 128|256 with n_in 128|256|<=64; n_out <= 4 with n_in 128|256)",
                  (long long)P, n_out, n_in);
     HNRF_REQUIRE(ldz >= n_out && ldx >= n_in && ldw >= n_in, HNRF_E_ARG, "hnrf_mlp_dw: row stride below width");
     HNRF_REQUIRE(workspace_bytes >= hnrf_mlp_dw_workspace_bytes(P, n_out, n_in), HNRF_E_ARG,
                  "hnrf_mlp_dw: workspace too small");
-    if (n_in > 64)
+    if (n_in > 64 && n_out > 4)
         HNRF_REQUIRE(((uintptr_t)X & 15) == 0 && ldx % 4 == 0, HNRF_E_ARG,
                      "hnrf_mlp_dw: X must be 16-byte aligned with a row stride that is a multiple of 4");
     float* part = (float*)workspace;
@@ -537,7 +746,13 @@ extern "C" int hnrf_mlp_dw(const float* dZ, int64_t ldz, const float* X, int64_t
 #define HNRF_DW(OT, IB)                                                                                        \
     hipLaunchKernelGGL((mlp_dw_kernel<OT, IB>), dim3(pl.nsplit), dim3(256), 0, st, dZ, ldz, X, ldx, n_in, P, \
                        pl.per_wg, part, db ? dbpart : nullptr)
-    if (n_out <= 4) {
+#define HNRF_DW16(OT, IB)                                                                                       \
+    hipLaunchKernelGGL((mlp_dw16_kernel<OT, IB>), dim3(pl.nsplit), dim3(256), 0, st, dZ, ldz, X, ldx, P, pl.per_wg, \
+                       dz_amax, n_amax, part, db ? dbpart : nullptr)
+    if (f16) {
+        if (n_out == 256) { if (n_in == 256) HNRF_DW16(2, 2); else HNRF_DW16(2, 1); }
+        else { if (n_in == 256) HNRF_DW16(1, 2); else HNRF_DW16(1, 1); }
+    } else if (n_out <= 4) {
         if (n_in == 256)
             hipLaunchKernelGGL(mlp_dw_head_kernel<256>, dim3(pl.nsplit), dim3(256), 0, st, dZ, ldz, n_out, X, ldx, P,
                                pl.per_wg, part, db ? dbpart : nullptr);
@@ -550,6 +765,7 @@ extern "C" int hnrf_mlp_dw(const float* dZ, int64_t ldz, const float* X, int64_t
         if (n_in == 256) HNRF_DW(1, 2); else if (n_in == 128) HNRF_DW(1, 1); else HNRF_DW(1, 0);
     }
 #undef HNRF_DW
+#undef HNRF_DW16
     int rc = check_launch("hnrf_mlp_dw");
     if (rc) return rc;
     const int nblk = pl.now * pl.nip / 64 + (db ? (pl.now + 63) / 64 : 0);
@@ -604,7 +820,7 @@ extern "C" int hnrf_nonrigid_bwd_pack(const float* const* weights, void* packed,
 }
 
 extern "C" int hnrf_canonical_bwd(const float* xyz, const float* d_raw, const uint32_t* relu_bits, const void* packed,
-                                  int64_t P, float* dZ, float* d_xyz, void* stream) {
+                                  int64_t P, float* dZ, float* d_xyz, float* dz_amax, void* stream) {
     HNRF_REQUIRE(xyz && d_raw && relu_bits && packed && dZ && d_xyz, HNRF_E_ARG, "hnrf_canonical_bwd: null pointer");
     HNRF_REQUIRE(P >= 0, HNRF_E_ARG, "hnrf_canonical_bwd: bad P");
     HNRF_REQUIRE((((uintptr_t)d_raw | (uintptr_t)relu_bits | (uintptr_t)dZ | (uintptr_t)packed) & 15) == 0, HNRF_E_ARG,
@@ -612,14 +828,18 @@ extern "C" int hnrf_canonical_bwd(const float* xyz, const float* d_raw, const ui
     if (P == 0) return HNRF_OK;
     const int64_t blocks = (P + 127) / 128;
     HNRF_REQUIRE(blocks < 2147483647LL, HNRF_E_ARG, "hnrf_canonical_bwd: too many samples");
+    if (dz_amax && hipMemsetAsync(dz_amax, 0, 8 * HNRF_AMAX_SLOTS * sizeof(float), (hipStream_t)stream) != hipSuccess) {
+        set_error("hnrf_canonical_bwd: memset failed");
+        return HNRF_E_LAUNCH;
+    }
     hipLaunchKernelGGL(canonical_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, xyz,
-                       (const float4*)d_raw, relu_bits, (const float*)packed, P, dZ, d_xyz);
+                       (const float4*)d_raw, relu_bits, (const float*)packed, P, dZ, d_xyz, dz_amax);
     return check_launch("hnrf_canonical_bwd");
 }
 
 extern "C" int hnrf_nonrigid_bwd(const float* x_skel, const float* hann_w, const float* d_xyz,
                                  const uint32_t* relu_bits, const void* packed, int64_t P, float* dZ,
-                                 float* d_x_skel, void* stream) {
+                                 float* d_x_skel, float* dz_amax, void* stream) {
     HNRF_REQUIRE(x_skel && hann_w && d_xyz && relu_bits && packed && dZ && d_x_skel, HNRF_E_ARG,
                  "hnrf_nonrigid_bwd: null pointer");
     HNRF_REQUIRE(P >= 0, HNRF_E_ARG, "hnrf_nonrigid_bwd: bad P");
@@ -628,7 +848,11 @@ extern "C" int hnrf_nonrigid_bwd(const float* x_skel, const float* hann_w, const
     if (P == 0) return HNRF_OK;
     const int64_t blocks = (P + 127) / 128;
     HNRF_REQUIRE(blocks < 2147483647LL, HNRF_E_ARG, "hnrf_nonrigid_bwd: too many samples");
+    if (dz_amax && hipMemsetAsync(dz_amax, 0, 6 * HNRF_AMAX_SLOTS * sizeof(float), (hipStream_t)stream) != hipSuccess) {
+        set_error("hnrf_nonrigid_bwd: memset failed");
+        return HNRF_E_LAUNCH;
+    }
     hipLaunchKernelGGL(nonrigid_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x_skel, hann_w,
-                       d_xyz, relu_bits, (const float*)packed, P, dZ, d_x_skel);
+                       d_xyz, relu_bits, (const float*)packed, P, dZ, d_x_skel, dz_amax);
     return check_launch("hnrf_nonrigid_bwd");
 }

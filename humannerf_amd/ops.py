@@ -245,7 +245,8 @@ def pe_bwd(x, g, hann_w, n_bands, include_input, out=None):
 
 
 def canonical_bwd(xyz, d_raw, bits, weights):
-    """dX chain of the canonical MLP: returns dZ (8,P,256) and d_xyz (P,3).  bits: sign masks from canonical_train."""
+    """dX chain of the canonical MLP: returns dZ (8,P,256), d_xyz (P,3) and amax (8,64) (max over row l bounds
+    |dZ_l|).  bits: sign masks from canonical_train."""
     lib = _lib.load()
     _chk(xyz, d_raw, *weights)
     P = xyz.numel() // 3
@@ -255,13 +256,14 @@ def canonical_bwd(xyz, d_raw, bits, weights):
     _lib.check(lib.hnrf_canonical_bwd_pack(_ptr_array(weights), _ptr(packed), _stream()), 'hnrf_canonical_bwd_pack')
     dZ = torch.empty(8, P, 256, device=xyz.device)
     d_xyz = torch.empty(P, 3, device=xyz.device)
+    amax = torch.empty(8, 64, device=xyz.device)
     _lib.check(lib.hnrf_canonical_bwd(_ptr(xyz), _ptr(d_raw), bits.data_ptr(), _ptr(packed), P, _ptr(dZ), _ptr(d_xyz),
-                                      _stream()), 'hnrf_canonical_bwd')
-    return dZ, d_xyz
+                                      _ptr(amax), _stream()), 'hnrf_canonical_bwd')
+    return dZ, d_xyz, amax
 
 
 def nonrigid_bwd(x_skel, hann_w, d_xyz, bits, weights):
-    """dX chain of the non-rigid MLP: returns dZ (6,P,128) and d_x_skel (P,3) (identity path included)."""
+    """dX chain of the non-rigid MLP: returns dZ (6,P,128), d_x_skel (P,3) (identity path included), amax (6,64)."""
     lib = _lib.load()
     _chk(x_skel, hann_w, d_xyz, *weights)
     P = x_skel.numel() // 3
@@ -271,17 +273,20 @@ def nonrigid_bwd(x_skel, hann_w, d_xyz, bits, weights):
     _lib.check(lib.hnrf_nonrigid_bwd_pack(_ptr_array(weights), _ptr(packed), _stream()), 'hnrf_nonrigid_bwd_pack')
     dZ = torch.empty(6, P, 128, device=x_skel.device)
     d_x_skel = torch.empty(P, 3, device=x_skel.device)
+    amax = torch.empty(6, 64, device=x_skel.device)
     _lib.check(lib.hnrf_nonrigid_bwd(_ptr(x_skel), _ptr(hann_w), _ptr(d_xyz), bits.data_ptr(), _ptr(packed), P, _ptr(dZ),
-                                     _ptr(d_x_skel), _stream()), 'hnrf_nonrigid_bwd')
-    return dZ, d_x_skel
+                                     _ptr(d_x_skel), _ptr(amax), _stream()), 'hnrf_nonrigid_bwd')
+    return dZ, d_x_skel, amax
 
 
 _dw_ws = {}
 
 
-def mlp_dw(dZ, X, dW_out=None, want_db=True):
+def mlp_dw(dZ, X, dW_out=None, want_db=True, mode='f32', dz_amax=None):
     """dW = dZ^T X (and db = column sums of dZ) for one nn.Linear: dZ [P, n_out], X [P, n_in], row-major views
-    whose last dimension is contiguous.  ``dW_out``: optional [n_out, >= n_in] view to write into (row stride kept)."""
+    whose last dimension is contiguous.  ``dW_out``: optional [n_out, >= n_in] view to write into (row stride kept).
+    mode 'f16x3' (matrix-shaped layers only, others fall back to fp32 MFMA) needs ``dz_amax``: a device scalar
+    tensor whose maximum bounds |dZ| (one row of the chain kernels' amax output)."""
     lib = _lib.load()
     assert dZ.dtype == torch.float32 and X.dtype == torch.float32 and dZ.is_cuda and X.is_cuda
     assert dZ.dim() == 2 and X.dim() == 2 and dZ.stride(1) == 1 and X.stride(1) == 1 and dZ.shape[0] == X.shape[0]
@@ -298,7 +303,10 @@ def mlp_dw(dZ, X, dW_out=None, want_db=True):
     ws = _dw_ws.get(key)
     if ws is None or ws.numel() < need:
         ws = _dw_ws[key] = torch.empty(need, dtype=torch.uint8, device=dZ.device)
+    if mode == 'f16x3' and dz_amax is None:
+        dz_amax = dZ.abs().amax().reshape(1)
     _lib.check(lib.hnrf_mlp_dw(dZ.data_ptr(), dZ.stride(0), X.data_ptr(), X.stride(0), P, n_out, n_in,
+                               MLP_MODES[mode], _ptr(dz_amax), 0 if dz_amax is None else dz_amax.numel(),
                                dW_out.data_ptr(), dW_out.stride(0), _ptr(db), ws.data_ptr(), ws.numel(), _stream()),
                'hnrf_mlp_dw')
     return dW_out, db

@@ -196,10 +196,14 @@ int hnrf_sample_warp_bwd(const float* rays_o, const float* rays_d, const float* 
  *  column blocks of a skip layer's weight are two calls).  Built shapes: n_out 128 | 256 with
  *  n_in 128 | 256 (X 16-byte aligned, ldx % 4 == 0) or n_in <= 64 (any ldx: the PE matrices);
  *  n_out <= 4 (the sigma/rgb and offset heads) with n_in 128 | 256.
- *  fp32 MFMA, deterministic (fixed-order slice reduction).  workspace: hnrf_mlp_dw_workspace_bytes. */
+ *  mode HNRF_MLP_F32: fp32 MFMA.  HNRF_MLP_F16X3: split-f16 MFMA at fp32-class accuracy for the matrix-shaped
+ *  layers (n_out, n_in in {128, 256}; other shapes silently use the fp32 kernels); needs dz_amax = n_amax device
+ *  floats whose maximum is >= max |dZ| (one row of hnrf_*_bwd's dz_amax), and |X| <= 65504.  Deterministic (fixed-order slice reduction).
+ *  workspace: hnrf_mlp_dw_workspace_bytes (covers both modes). */
 size_t hnrf_mlp_dw_workspace_bytes(int64_t P, int n_out, int n_in);
 int hnrf_mlp_dw(const float* dZ, int64_t ldz, const float* X, int64_t ldx, int64_t P, int n_out, int n_in,
-                float* dW, int64_t ldw, float* db, void* workspace, size_t workspace_bytes, void* stream);
+                int mode, const float* dz_amax, int n_amax, float* dW, int64_t ldw, float* db, void* workspace,
+                size_t workspace_bytes, void* stream);
 
 /* Backward through all layers of one MLP (the dX chain of autograd over mlp_rgb_sigma.py / mlp_offset.py),
  * register-resident like the forward, with the backward of the positional encoding fused.
@@ -214,10 +218,13 @@ size_t hnrf_canonical_bwd_packed_bytes(void);
 size_t hnrf_nonrigid_bwd_packed_bytes(void);
 int hnrf_canonical_bwd_pack(const float* const* weights, void* packed, void* stream);
 int hnrf_nonrigid_bwd_pack(const float* const* weights, void* packed, void* stream);
+/* dz_amax (nullable): [L][HNRF_AMAX_SLOTS] floats; max over row l bounds |dZ_l| (the scale input of
+ * hnrf_mlp_dw in HNRF_MLP_F16X3 mode). */
+#define HNRF_AMAX_SLOTS 64
 int hnrf_canonical_bwd(const float* xyz, const float* d_raw, const uint32_t* relu_bits, const void* packed,
-                       int64_t P, float* dZ, float* d_xyz, void* stream);
+                       int64_t P, float* dZ, float* d_xyz, float* dz_amax, void* stream);
 int hnrf_nonrigid_bwd(const float* x_skel, const float* hann_w, const float* d_xyz, const uint32_t* relu_bits,
-                      const void* packed, int64_t P, float* dZ, float* d_x_skel, void* stream);
+                      const void* packed, int64_t P, float* dZ, float* d_x_skel, float* dz_amax, void* stream);
 
 /* =============================== in front of the path ===============================
  * Ray generation + bbox intersection + order-preserving compaction (get_rays_from_KRT,

@@ -200,8 +200,9 @@ def test_canonical_backward_chain_and_weight_gradients_match_autograd(mode):
     T = lambda a: torch.from_numpy(a).to(dev())
     ws, bs = [T(st[n + '.weight']) for n in names], [T(st[n + '.bias']) for n in names]
     raw, pe, acts, bits = ops.canonical_train(T(xyz), ops.canonical_pack(ws, bs, mode), mode)
-    dZ, d_xyz = ops.canonical_bwd(T(xyz), T(g_raw), bits, ws)
-    gW, gb = _weight_grads(dZ, acts, pe, T(g_raw), ws, skip_layer=5, skip_order='pe_first')
+    dZ, d_xyz, amax = ops.canonical_bwd(T(xyz), T(g_raw), bits, ws)
+    assert torch.equal(amax.amax(1), dZ.abs().amax(dim=(1, 2)))
+    gW, gb = _weight_grads(dZ, acts, pe, T(g_raw), ws, skip_layer=5, skip_order='pe_first', amax=amax, mode=mode)
 
     x64 = torch.from_numpy(xyz).double().requires_grad_(True)
     w64 = [torch.from_numpy(st[n + '.weight']).double().requires_grad_(True) for n in names]
@@ -235,8 +236,9 @@ def test_nonrigid_backward_chain_and_weight_gradients_match_autograd(mode):
     T = lambda a: torch.from_numpy(a).to(dev())
     ws, bs = [T(st[n + '.weight']) for n in names], [T(st[n + '.bias']) for n in names]
     xyz, off, pe, acts, bits = ops.nonrigid_train(T(x), T(hann), ops.nonrigid_pack(ws, bs, T(cond), mode), mode)
-    dZ, d_x = ops.nonrigid_bwd(T(x), T(hann), T(g_xyz), bits, ws)
-    gW, gb = _weight_grads(dZ, acts, pe, T(g_xyz), ws, skip_layer=4, skip_order='h_first')
+    dZ, d_x, amax = ops.nonrigid_bwd(T(x), T(hann), T(g_xyz), bits, ws)
+    assert torch.equal(amax.amax(1), dZ.abs().amax(dim=(1, 2)))
+    gW, gb = _weight_grads(dZ, acts, pe, T(g_xyz), ws, skip_layer=4, skip_order='h_first', amax=amax, mode=mode)
     gW[0] = torch.cat([gb[0][:, None] * T(cond).reshape(1, -1), gW[0]], dim=1)
 
     x64 = torch.from_numpy(x).double().requires_grad_(True)
