@@ -130,6 +130,43 @@ class _CanonicalParams(nn.Module):
         return [m for m in self.pts_linears if isinstance(m, nn.Linear)] + [self.output_linear[0]]
 
 
+class _ConvT3dK4S2P1(torch.autograd.Function):
+    """Forward: the library's transposed convolution.  Backward: two plain GEMMs on the weight's NATIVE layout.
+
+    With col[i, (co, k)] = g[co, 2 i - 1 + k] (the 4x4x4 stride-2 windows of the padded output gradient, one
+    strided-view copy) the adjoint of ConvTranspose3d(4, 2, 1) is
+        dx[i, ci]      = sum_(co,k) col[i, (co,k)] W[ci, (co,k)]          (D H W x 64 Cout) @ (64 Cout x Cin)
+        dW[ci, (co,k)] = sum_i      x[i, ci]       col[i, (co,k)]          (Cin x D H W) @ (D H W x 64 Cout)
+    -- no permuted copy of the 254 MB of decoder weights.  MIOpen has no tuned backward for these batch-1
+    transposed 3-D convolutions: its solver search runs seconds of naive kernels on a fresh machine and settles
+    on anything from 4 to 13 ms per training step for 20 GFLOP of work."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        ctx.save_for_backward(x, weight)
+        return F.conv_transpose3d(x, weight, bias, stride=2, padding=1)
+
+    @staticmethod
+    def backward(ctx, g):
+        x, weight = ctx.saved_tensors
+        _, cin, D, H, W = x.shape
+        cout = weight.shape[1]
+        g3 = g[0]
+        col = F.pad(g3, (1, 1, 1, 1, 1, 1)).unfold(1, 4, 2).unfold(2, 4, 2).unfold(3, 4, 2)   # (Cout, D, H, W, 4,4,4)
+        col = col.permute(1, 2, 3, 0, 4, 5, 6).reshape(D * H * W, cout * 64)
+        wm = weight.reshape(cin, cout * 64)
+        xm = x[0].reshape(cin, D * H * W)
+        dx = (col @ wm.t()).t().reshape(1, cin, D, H, W)
+        dw = (xm @ col).reshape(cin, cout, 4, 4, 4)
+        return dx, dw, g3.sum(dim=(1, 2, 3))
+
+
+def conv_transpose3d_k4s2p1(x, weight, bias):
+    """nn.ConvTranspose3d(kernel 4, stride 2, padding 1) of a batch-1 volume, x (1, Cin, D, H, W), with the
+    GEMM backward above."""
+    return _ConvT3dK4S2P1.apply(x, weight, bias)
+
+
 class _ConvDecoder3D(nn.Module):
     """core/utils/network_util.py:12-50."""
 
@@ -149,12 +186,15 @@ class _ConvDecoder3D(nn.Module):
         _init_sequence(self.block_conv)
 
     def forward(self, embedding):
-        return self.block_conv(self.block_mlp(embedding).view(-1, 1024, 1, 1, 1))
+        h = self.block_mlp(embedding).view(-1, 1024, 1, 1, 1)
+        for m in self.block_conv:                                   # parameters live in the reference's modules
+            h = conv_transpose3d_k4s2p1(h, m.weight, m.bias) if isinstance(m, nn.ConvTranspose3d) else m(h)
+        return h
 
 
 class MotionWeightVolumeDecoder(nn.Module):
-    """mweight_vol_decoders/deconv_vol_decoder.py:8-33 (stays PyTorch/MIOpen:
-    9 GFLOP once per frame against 40 TFLOP of per-sample work)."""
+    """mweight_vol_decoders/deconv_vol_decoder.py:8-33 (9 GFLOP once per frame against 40 TFLOP of per-sample
+    work: stays PyTorch, with the transposed convolutions as batched GEMMs)."""
 
     def __init__(self, embedding_size=256, volume_size=32, total_bones=24):
         super().__init__()

@@ -134,3 +134,21 @@ def test_patch_unpack_and_loss():
     assert torch.allclose(img[0][~masks[0]], bg.expand(int((~masks[0]).sum()), 3))
     loss, parts = train.image_loss(img, targets, None)
     assert set(parts) == {'mse'} and abs(float(loss) - 0.2 * float(((img - targets) ** 2).mean())) < 1e-7
+
+
+def test_conv_transpose_as_batched_gemm_matches_torch():
+    """network.conv_transpose3d_k4s2p1 (the weight-volume decoder's layers, network_util.py:12-50) against
+    F.conv_transpose3d in fp64: output and all three gradients."""
+    import torch.nn.functional as F
+    from humannerf_amd.network import conv_transpose3d_k4s2p1
+    torch.manual_seed(0)
+    for cin, cout, dims in ((6, 5, (1, 1, 1)), (4, 3, (2, 3, 2)), (8, 25, (4, 4, 4))):
+        x = torch.randn(1, cin, *dims, dtype=torch.float64, requires_grad=True)
+        w = torch.randn(cin, cout, 4, 4, 4, dtype=torch.float64, requires_grad=True)
+        b = torch.randn(cout, dtype=torch.float64, requires_grad=True)
+        ref = F.conv_transpose3d(x, w, b, stride=2, padding=1)
+        got = conv_transpose3d_k4s2p1(x, w, b)
+        assert got.shape == ref.shape and (got - ref).abs().max() < 1e-12
+        g = torch.randn_like(ref)
+        for a, r in zip(torch.autograd.grad(got, (x, w, b), g), torch.autograd.grad(ref, (x, w, b), g)):
+            assert (a - r).abs().max() < 1e-11
