@@ -76,7 +76,8 @@ class RenderRays(torch.autograd.Function):
         # canonical MLP (skip layer 5 takes [PE63 | h]): dX chain with the PE backward fused, then the weight gradients
         d_raw = d_raw.view(P, 4)
         dw_mode = amd_option('train_dw_mode', 'f16x3')
-        dZc, d_xyz, amax_c = ops.canonical_bwd(xyz.reshape(P, 3), d_raw, bits_c, cn_w)
+        dZc, d_xyz, amax_c = ops.canonical_bwd(xyz.reshape(P, 3), d_raw, bits_c, cn_w,
+                                               amd_option('train_chain_mode', 'f16x3'))
         gWc, gbc = _weight_grads(dZc, acts_c, pe_c, d_raw, cn_w, skip_layer=5, skip_order='pe_first', amax=amax_c,
                                  mode=dw_mode)
         del dZc

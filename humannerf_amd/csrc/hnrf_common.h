@@ -43,4 +43,9 @@ int nonrigid16_fwd(const float* x_skel, const float* hann_w, const void* packed,
 int nonrigid16_fwd_train(const float* x_skel, const float* hann_w, const void* packed, int64_t P, float* xyz,
                          float* offsets, float* pe_out, float* acts, uint32_t* relu_bits, hipStream_t st);
 
+size_t canonical16_bwd_bytes();
+int canonical16_bwd_pack(const float* const* w, void* packed, hipStream_t st);
+int canonical16_bwd(const float* xyz, const float* d_raw, const uint32_t* relu_bits, const void* packed, int64_t P,
+                    const float* d_raw_amax, float* dZ, float* d_xyz, float* dz_amax, hipStream_t st);
+
 }  // namespace hnrf

@@ -774,13 +774,19 @@ extern "C" int hnrf_mlp_dw(const float* dZ, int64_t ldz, const float* X, int64_t
     return check_launch("hnrf_mlp_dw (reduce)");
 }
 
-extern "C" size_t hnrf_canonical_bwd_packed_bytes(void) { return (size_t)CB_FLOATS * sizeof(float); }
+extern "C" size_t hnrf_canonical_bwd_packed_bytes(int mode) {
+    if (mode == HNRF_MLP_F16X3) return canonical16_bwd_bytes();
+    return mode == HNRF_MLP_F32 ? (size_t)CB_FLOATS * sizeof(float) : 0;
+}
 extern "C" size_t hnrf_nonrigid_bwd_packed_bytes(void) { return (size_t)NB_FLOATS * sizeof(float); }
 
-extern "C" int hnrf_canonical_bwd_pack(const float* const* weights, void* packed, void* stream) {
+extern "C" int hnrf_canonical_bwd_pack(const float* const* weights, int mode, void* packed, void* stream) {
     HNRF_REQUIRE(weights && packed, HNRF_E_ARG, "hnrf_canonical_bwd_pack: null pointer");
+    HNRF_REQUIRE(mode == HNRF_MLP_F32 || mode == HNRF_MLP_F16X3, HNRF_E_UNSUPPORTED,
+                 "hnrf_canonical_bwd_pack: mode %d not built", mode);
     for (int i = 0; i < 9; ++i) HNRF_REQUIRE(weights[i], HNRF_E_ARG, "hnrf_canonical_bwd_pack: null layer %d", i);
     hipStream_t st = (hipStream_t)stream;
+    if (mode == HNRF_MLP_F16X3) return canonical16_bwd_pack(weights, packed, st);
     float* out = (float*)packed;
     if (hipMemsetAsync(out + CB_END, 0, PF * 256 * sizeof(float), st) != hipSuccess) {
         set_error("hnrf_canonical_bwd_pack: memset failed");
@@ -820,8 +826,13 @@ extern "C" int hnrf_nonrigid_bwd_pack(const float* const* weights, void* packed,
 }
 
 extern "C" int hnrf_canonical_bwd(const float* xyz, const float* d_raw, const uint32_t* relu_bits, const void* packed,
-                                  int64_t P, float* dZ, float* d_xyz, float* dz_amax, void* stream) {
+                                  int mode, const float* d_raw_amax, int64_t P, float* dZ, float* d_xyz,
+                                  float* dz_amax, void* stream) {
     HNRF_REQUIRE(xyz && d_raw && relu_bits && packed && dZ && d_xyz, HNRF_E_ARG, "hnrf_canonical_bwd: null pointer");
+    HNRF_REQUIRE(mode == HNRF_MLP_F32 || mode == HNRF_MLP_F16X3, HNRF_E_UNSUPPORTED,
+                 "hnrf_canonical_bwd: mode %d not built", mode);
+    HNRF_REQUIRE(mode != HNRF_MLP_F16X3 || d_raw_amax, HNRF_E_ARG,
+                 "hnrf_canonical_bwd: HNRF_MLP_F16X3 needs d_raw_amax (device scalar >= max |d_raw|)");
     HNRF_REQUIRE(P >= 0, HNRF_E_ARG, "hnrf_canonical_bwd: bad P");
     HNRF_REQUIRE((((uintptr_t)d_raw | (uintptr_t)relu_bits | (uintptr_t)dZ | (uintptr_t)packed) & 15) == 0, HNRF_E_ARG,
                  "hnrf_canonical_bwd: d_raw, relu_bits, dZ, packed must be 16-byte aligned");
@@ -832,6 +843,8 @@ extern "C" int hnrf_canonical_bwd(const float* xyz, const float* d_raw, const ui
         set_error("hnrf_canonical_bwd: memset failed");
         return HNRF_E_LAUNCH;
     }
+    if (mode == HNRF_MLP_F16X3)
+        return canonical16_bwd(xyz, d_raw, relu_bits, packed, P, d_raw_amax, dZ, d_xyz, dz_amax, (hipStream_t)stream);
     hipLaunchKernelGGL(canonical_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, xyz,
                        (const float4*)d_raw, relu_bits, (const float*)packed, P, dZ, d_xyz, dz_amax);
     return check_launch("hnrf_canonical_bwd");

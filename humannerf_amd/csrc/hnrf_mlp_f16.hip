@@ -181,7 +181,8 @@ __device__ __forceinline__ void wait_dma_keep(int keep) {
         HNRF_VMCNT_CASE(4) HNRF_VMCNT_CASE(6) HNRF_VMCNT_CASE(8) HNRF_VMCNT_CASE(10)
         // training variant: the 4 activation stores per finished tile sit in the same in-order queue
         HNRF_VMCNT_CASE(12) HNRF_VMCNT_CASE(14) HNRF_VMCNT_CASE(16) HNRF_VMCNT_CASE(18) HNRF_VMCNT_CASE(20)
-        HNRF_VMCNT_CASE(22) HNRF_VMCNT_CASE(24) HNRF_VMCNT_CASE(26)
+        HNRF_VMCNT_CASE(22) HNRF_VMCNT_CASE(24) HNRF_VMCNT_CASE(26) HNRF_VMCNT_CASE(28) HNRF_VMCNT_CASE(30)
+        HNRF_VMCNT_CASE(32) HNRF_VMCNT_CASE(34) HNRF_VMCNT_CASE(36) HNRF_VMCNT_CASE(38) HNRF_VMCNT_CASE(40)
         default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
     }
 #undef HNRF_VMCNT_CASE
@@ -279,7 +280,46 @@ struct SaveCtx {
     float* row;
     uint32_t* bits;
     float sv0, sv1;            // even pair of the current float4
+    // backward chain (layer16 SAVE = 2 / 3): sign-mask words of the stage, 1 / scale of the gradient, running
+    // maximum of the |dZ| stored by the stage, fp32 outputs of a positional-encoding stage
+    uint32_t mask[4];
+    float descale, amax;
+    float fout[32];
 };
+
+// Backward epilogue of one accumulator pair: x = (acc1 + acc2 / 2^11) * relu'(mask bit), split for the next stage;
+// hands back the two (still scaled) values.
+__device__ __forceinline__ void epi_pair_m(const f32x16& a1, const f32x16& a2, int i, uint32_t mbits, h16x8& hi,
+                                           h16x8& lo, float& x0o, float& x1o) {
+    float x0 = fmaf(a2[2 * i], LO_INV, a1[2 * i]);
+    float x1 = fmaf(a2[2 * i + 1], LO_INV, a1[2 * i + 1]);
+    x0 = (mbits >> (2 * i)) & 1u ? __builtin_amdgcn_fmed3f(x0, -65504.f, 65504.f) : 0.f;
+    x1 = (mbits >> (2 * i + 1)) & 1u ? __builtin_amdgcn_fmed3f(x1, -65504.f, 65504.f) : 0.f;
+    const h16x2 hh = __builtin_convertvector(f32x2{x0, x1}, h16x2);
+    const float r0 = fmaf(x0, LO_SCALE, -((float)hh[0] * LO_SCALE));
+    const float r1 = fmaf(x1, LO_SCALE, -((float)hh[1] * LO_SCALE));
+    const h16x2 ll = __builtin_convertvector(f32x2{r0, r1}, h16x2);
+    const int e = 2 * (i & 3);
+    hi[e] = hh[0];
+    hi[e + 1] = hh[1];
+    lo[e] = ll[0];
+    lo[e + 1] = ll[1];
+    x0o = x0;
+    x1o = x1;
+}
+
+// dZ store of the backward chain: un-scaled fp32, 4 values per store like save_pair; tracks max |dZ|
+__device__ __forceinline__ void save_pair_b(SaveCtx& sc, int t, int i, float x0, float x1) {
+    x0 *= sc.descale;
+    x1 *= sc.descale;
+    sc.amax = fmaxf(sc.amax, fmaxf(fabsf(x0), fabsf(x1)));
+    if (i & 1) {
+        *reinterpret_cast<f32x4*>(sc.row + 32 * t + 8 * (i >> 1)) = f32x4{sc.sv0, sc.sv1, x0, x1};
+    } else {
+        sc.sv0 = x0;
+        sc.sv1 = x1;
+    }
+}
 
 template <int NW>
 __device__ __forceinline__ void save_pair(SaveCtx& sc, uint32_t (&bw)[NW], int t, int i, float x0, float x1) {
@@ -302,7 +342,7 @@ __device__ __forceinline__ void save_pair(SaveCtx& sc, uint32_t (&bw)[NW], int t
 //     96 cycles of one k-step's MFMAs);
 //   * the VALU epilogue of tile t-1 (8 pair-units) is spread over the k-steps of tile t,
 //     so it runs in the shadow of the MFMAs; only the last tile's epilogue is exposed.
-template <int NT, int TPS, int NKA, int NKB, bool RELU, bool SAVE = false, int NB, int NO>
+template <int NT, int TPS, int NKA, int NKB, bool RELU, int SAVE = 0, int NB, int NO>
 __device__ __forceinline__ void layer16(Pipe& p, int nb1, int nb2, const h16x8 (&bh)[NB], const h16x8 (&bl)[NB],
                                         h16x8 (&oh)[NO], h16x8 (&ol)[NO], float (&last)[16], SaveCtx* sc = nullptr) {
     static_assert(NB >= (NKB > 0 ? NKB : 1) && NO >= 2 * NT && NT % TPS == 0, "bad layer shape");
@@ -336,7 +376,7 @@ __device__ __forceinline__ void layer16(Pipe& p, int nb1, int nb2, const h16x8 (
             const unsigned pe = p.lds_base + p.pe_off + p.wave * (PE_STASH / 4) + lane * 16;
             f32x16 acc1 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
             f32x16 acc2 = acc1;
-            if (NT > 1) {
+            if (NT > 1 && SAVE < 2) {                      // (the backward stages have no bias)
                 const unsigned bp = p.lds_base + p.bias_off + tt * 128 + (lane >> 5) * 16;
                 const f32x4 b0 = lds_ld4f(bp), b1 = lds_ld4f(bp + 32), b2 = lds_ld4f(bp + 64), b3 = lds_ld4f(bp + 96);
                 acc1 = f32x16{b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w,
@@ -395,16 +435,25 @@ __device__ __forceinline__ void layer16(Pipe& p, int nb1, int nb2, const h16x8 (
 #pragma unroll
                     for (int i = 0; i < 8; ++i)
                         if ((i * NK) / 8 == ks) {
-                            if constexpr (SAVE) {
+                            if constexpr (SAVE == 1) {
                                 float x0, x1;
                                 epi_pair_x<RELU>(pacc1, pacc2, i, oh[2 * (t - 1) + (i >> 2)], ol[2 * (t - 1) + (i >> 2)],
                                                  x0, x1);
                                 save_pair(*sc, bw, t - 1, i, x0, x1);
+                            } else if constexpr (SAVE == 2) {
+                                float x0, x1;
+                                epi_pair_m(pacc1, pacc2, i, sc->mask[(t - 1) >> 1] >> (16 * ((t - 1) & 1)),
+                                           oh[2 * (t - 1) + (i >> 2)], ol[2 * (t - 1) + (i >> 2)], x0, x1);
+                                save_pair_b(*sc, t - 1, i, x0, x1);
+                            } else if constexpr (SAVE == 3) {
+                                sc->fout[16 * (t - 1) + 2 * i] = fmaf(pacc2[2 * i], LO_INV, pacc1[2 * i]);
+                                sc->fout[16 * (t - 1) + 2 * i + 1] = fmaf(pacc2[2 * i + 1], LO_INV, pacc1[2 * i + 1]);
                             } else
                             epi_pair<RELU>(pacc1, pacc2, i, oh[2 * (t - 1) + (i >> 2)], ol[2 * (t - 1) + (i >> 2)]);
                             // pin the result here: without a use in this block hipcc sinks the whole
                             // epilogue to the first consumer (the next layer), out of the MFMA shadow
-                            asm volatile("" : "+v"(oh[2 * (t - 1) + (i >> 2)]), "+v"(ol[2 * (t - 1) + (i >> 2)]));
+                            if constexpr (SAVE != 3)
+                                asm volatile("" : "+v"(oh[2 * (t - 1) + (i >> 2)]), "+v"(ol[2 * (t - 1) + (i >> 2)]));
                         }
                 }
                 // issue order inside the k-step: keep the matrix pipe fed -- one MFMA, then <= 6 of the
@@ -428,7 +477,7 @@ __device__ __forceinline__ void layer16(Pipe& p, int nb1, int nb2, const h16x8 (
         // slab n+1 landed (only the pieces of slab n+2 may still fly); every wave done with slab n.
         // SAVE: the activation stores issued during this slab (4 per tile that had a pending epilogue) are younger
         // than every piece of slab n+1 as well, so they may stay in flight too
-        const int n_st = SAVE ? 4 * (s == 0 ? TPS - 1 : TPS) : 0;
+        const int n_st = (SAVE == 1 || SAVE == 2) ? 4 * (s == 0 ? TPS - 1 : TPS) : 0;
         tile_sync(nissue / 4 + n_st);
         p.ph = p.ph == RING - 1 ? 0 : p.ph + 1;
         p.bias_off += TPS * 128;
@@ -439,14 +488,22 @@ __device__ __forceinline__ void layer16(Pipe& p, int nb1, int nb2, const h16x8 (
     } else {
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-            if constexpr (SAVE) {
+            if constexpr (SAVE == 1) {
                 float x0, x1;
                 epi_pair_x<RELU>(pacc1, pacc2, i, oh[2 * (NT - 1) + (i >> 2)], ol[2 * (NT - 1) + (i >> 2)], x0, x1);
                 save_pair(*sc, bw, NT - 1, i, x0, x1);
+            } else if constexpr (SAVE == 2) {
+                float x0, x1;
+                epi_pair_m(pacc1, pacc2, i, sc->mask[(NT - 1) >> 1] >> (16 * ((NT - 1) & 1)), oh[2 * (NT - 1) + (i >> 2)],
+                           ol[2 * (NT - 1) + (i >> 2)], x0, x1);
+                save_pair_b(*sc, NT - 1, i, x0, x1);
+            } else if constexpr (SAVE == 3) {
+                sc->fout[16 * (NT - 1) + 2 * i] = fmaf(pacc2[2 * i], LO_INV, pacc1[2 * i]);
+                sc->fout[16 * (NT - 1) + 2 * i + 1] = fmaf(pacc2[2 * i + 1], LO_INV, pacc1[2 * i + 1]);
             } else
             epi_pair<RELU>(pacc1, pacc2, i, oh[2 * (NT - 1) + (i >> 2)], ol[2 * (NT - 1) + (i >> 2)]);
         }
-        if constexpr (SAVE) {
+        if constexpr (SAVE == 1) {
 #pragma unroll
             for (int i = 0; i < (NT + 1) / 2; ++i) sc->bits[i] = bw[i];
         }
@@ -543,23 +600,23 @@ __global__ __launch_bounds__(256) void canonical_f16x3_kernel(const float* __res
 
     h16x8 hA_h[16], hA_l[16], hB_h[16], hB_l[16];
     float last[16];
-    layer16<8, 4, 4, 0, true, SAVE>(p, CNL16_NB_MID, CNL16_NB_MID, hB_h, hB_l, hA_h, hA_l, last, &sc);   // (hB unused: NKB = 0)
+    layer16<8, 4, 4, 0, true, SAVE ? 1 : 0>(p, CNL16_NB_MID, CNL16_NB_MID, hB_h, hB_l, hA_h, hA_l, last, &sc);   // (hB unused: NKB = 0)
     if constexpr (SAVE) { sc.row += act_stride; sc.bits += bit_stride; }
 #pragma unroll 1
     for (int l = 1; l <= 4; ++l) {
         const int nb = l == 4 ? CNL16_NB_L5 : CNL16_NB_MID;
-        layer16<8, 1, 0, 16, true, SAVE>(p, nb, nb, hA_h, hA_l, hB_h, hB_l, last, &sc);
+        layer16<8, 1, 0, 16, true, SAVE ? 1 : 0>(p, nb, nb, hA_h, hA_l, hB_h, hB_l, last, &sc);
         if constexpr (SAVE) { sc.row += act_stride; sc.bits += bit_stride; }
 #pragma unroll
         for (int i = 0; i < 16; ++i) { hA_h[i] = hB_h[i]; hA_l[i] = hB_l[i]; }
     }
-    layer16<8, 1, 4, 16, true, SAVE>(p, CNL16_NB_MID, CNL16_NB_MID, hA_h, hA_l, hB_h, hB_l, last, &sc);   // skip layer
+    layer16<8, 1, 4, 16, true, SAVE ? 1 : 0>(p, CNL16_NB_MID, CNL16_NB_MID, hA_h, hA_l, hB_h, hB_l, last, &sc);   // skip layer
     if constexpr (SAVE) { sc.row += act_stride; sc.bits += bit_stride; }
 #pragma unroll
     for (int i = 0; i < 16; ++i) { hA_h[i] = hB_h[i]; hA_l[i] = hB_l[i]; }
 #pragma unroll 1
     for (int l = 6; l <= 7; ++l) {
-        layer16<8, 1, 0, 16, true, SAVE>(p, CNL16_NB_MID, l == 7 ? 0 : CNL16_NB_MID, hA_h, hA_l, hB_h, hB_l, last, &sc);
+        layer16<8, 1, 0, 16, true, SAVE ? 1 : 0>(p, CNL16_NB_MID, l == 7 ? 0 : CNL16_NB_MID, hA_h, hA_l, hB_h, hB_l, last, &sc);
         if constexpr (SAVE) { sc.row += act_stride; sc.bits += bit_stride; }
 #pragma unroll
         for (int i = 0; i < 16; ++i) { hA_h[i] = hB_h[i]; hA_l[i] = hB_l[i]; }
@@ -630,20 +687,20 @@ __global__ __launch_bounds__(256) void nonrigid_f16x3_kernel(const float* __rest
 
     h16x8 hA_h[8], hA_l[8], hB_h[8], hB_l[8];
     float last[16];
-    layer16<4, 4, 4, 0, true, SAVE>(p, 0 /*already in flight*/, 2 * NR16_NB_MID, hB_h, hB_l, hA_h, hA_l, last, &sc);
+    layer16<4, 4, 4, 0, true, SAVE ? 1 : 0>(p, 0 /*already in flight*/, 2 * NR16_NB_MID, hB_h, hB_l, hA_h, hA_l, last, &sc);
     if constexpr (SAVE) { sc.row += act_stride; sc.bits += bit_stride; }
 #pragma unroll 1
     for (int l = 1; l <= 3; ++l) {
         // 128-wide tiles have only 8 k-steps: two tiles per slab halve the barriers per MFMA
         const int nb = l == 3 ? NR16_NB_L4 : 2 * NR16_NB_MID;
-        layer16<4, 2, 0, 8, true, SAVE>(p, nb, nb, hA_h, hA_l, hB_h, hB_l, last, &sc);
+        layer16<4, 2, 0, 8, true, SAVE ? 1 : 0>(p, nb, nb, hA_h, hA_l, hB_h, hB_l, last, &sc);
         if constexpr (SAVE) { sc.row += act_stride; sc.bits += bit_stride; }
 #pragma unroll
         for (int i = 0; i < 8; ++i) { hA_h[i] = hB_h[i]; hA_l[i] = hB_l[i]; }
     }
-    layer16<4, 1, 4, 8, true, SAVE>(p, 2 * NR16_NB_MID, 2 * NR16_NB_MID, hA_h, hA_l, hB_h, hB_l, last, &sc);    // skip layer
+    layer16<4, 1, 4, 8, true, SAVE ? 1 : 0>(p, 2 * NR16_NB_MID, 2 * NR16_NB_MID, hA_h, hA_l, hB_h, hB_l, last, &sc);    // skip layer
     if constexpr (SAVE) { sc.row += act_stride; sc.bits += bit_stride; }
-    layer16<4, 2, 0, 8, true, SAVE>(p, NR16_NB_MID, 0, hB_h, hB_l, hA_h, hA_l, last, &sc);
+    layer16<4, 2, 0, 8, true, SAVE ? 1 : 0>(p, NR16_NB_MID, 0, hB_h, hB_l, hA_h, hA_l, last, &sc);
     h16x8 dh[2], dl[2];
     layer16<1, 1, 0, 8, false>(p, 0, 0, hA_h, hA_l, dh, dl, last);
     const float* ob = reinterpret_cast<const float*>(packed + NR16_BIAS + NR16_BIAS_LDS);
@@ -657,6 +714,183 @@ __global__ __launch_bounds__(256) void nonrigid_f16x3_kernel(const float* __rest
             offsets[sample * 3 + 1] = o1;
             offsets[sample * 3 + 2] = o2;
         }
+    }
+}
+
+// ============================================================================ dX chain, split-f16
+// The backward chain of the canonical MLP (hnrf_mlp_bwd.hip has the fp32-MFMA version and the derivation) on the
+// same LDS-DMA weight pipeline as the forward: stage m multiplies W_{m+1}^T (transposed image, K order = the
+// register layout of the previous stage's output, hid_feat16) with dZ_{m+1}, applies relu' from the sign mask,
+// stores dZ_m (fp32, un-scaled) and hands the split result to the next stage.  Gradients are scaled by a power of
+// two so that max |d_raw| lands in [2, 4): 14 binary orders of head-room for growth through the layers, and
+// everything within 2^-16 of the running maximum keeps the full 22-bit split.  The two positional-encoding stages
+// (rows in PE K-step order) leave fp32 values for the fused PE backward.
+struct PackBwd16 {
+    const float* W;        // forward nn.Linear weight (n_out, n_in)
+    int n_out, n_in;
+    int NT, NK;            // tiles of 32 rows (forward in-features) / k-steps of 16 (forward out-features)
+    int row_kind;          // PE16_NONE: row rho <-> column col0 + rho; else rows in PE argument order
+    int col0;
+    int head;              // 1: K = the n_out (<= 4) head outputs, elements 0..3 of lane half 0 of k-step 0
+    int64_t off;           // byte offset of the stage's first slab
+};
+
+__global__ void pack_bwd16_kernel(PackBwd16 d, char* __restrict__ packed) {
+    const int slab_units = 2 * d.NK * 256;
+    const int64_t n = (int64_t)d.NT * slab_units;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int t = (int)(i / slab_units);
+    const int u = (int)(i % slab_units);
+    const int blk = u >> 8;
+    const int ks = blk >> 1, part = blk & 1;
+    const int lane = (u >> 2) & 63;
+    const int j0 = (u & 3) * 2;
+    const int h = lane >> 5;
+    const int rho = 32 * t + (lane & 31);
+    int col;
+    if (d.row_kind == PE16_NONE) {
+        col = d.col0 + rho;
+    } else {       // register (tile tt, r) on half hh holds row 32 tt + 8 (r >> 2) + 4 hh + (r & 3): PE argument 16 tt + r
+        const int tt = rho >> 5, w = rho & 31;
+        const int r = 4 * (w >> 3) + (w & 3), hh = (w >> 2) & 1;
+        const int c = pe_col16(d.row_kind, 16 * tt + r, hh);
+        col = c < 0 ? -1 : d.col0 + c;
+    }
+    _Float16 outv[2];
+    for (int e = 0; e < 2; ++e) {
+        const int j = j0 + e;
+        const int o = d.head ? ((ks == 0 && h == 0 && j < d.n_out) ? j : -1) : hid_feat16(ks, j, h);
+        float w = 0.f;
+        if (o >= 0 && o < d.n_out && col >= 0 && col < d.n_in) w = d.W[(int64_t)o * d.n_in + col];
+        const _Float16 hi = (_Float16)w;
+        const _Float16 lo = (_Float16)((w - (float)hi) * LO_SCALE);
+        outv[e] = part ? lo : hi;
+    }
+    *reinterpret_cast<h16x2*>(packed + d.off + ((int64_t)t * slab_units + u) * 4) = h16x2{outv[0], outv[1]};
+}
+
+// image: head (8 tiles x 2 blocks) | W7^T W6^T W5^T(hidden rows) (8 x 32 each) | W5^T PE rows (2 x 32) |
+//        W4^T .. W1^T (8 x 32 each) | W0^T PE rows (2 x 32)
+constexpr int64_t CB16_HEAD = 0;
+constexpr int64_t CB16_FULL = 8 * 32 * KB;
+constexpr int64_t CB16_PE = 2 * 32 * KB;
+constexpr int64_t CB16_L7 = CB16_HEAD + 16 * KB;
+constexpr int64_t CB16_L5P = CB16_L7 + 3 * CB16_FULL;
+constexpr int64_t CB16_L4 = CB16_L5P + CB16_PE;
+constexpr int64_t CB16_L0P = CB16_L4 + 4 * CB16_FULL;
+constexpr int64_t CB16_BYTES = CB16_L0P + CB16_PE;
+
+__device__ __forceinline__ void chain_amax(SaveCtx& sc, float* __restrict__ slot) {
+    float m = sc.amax;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+    if (slot != nullptr && lane_now() == 0) atomicMax(reinterpret_cast<unsigned int*>(slot), __float_as_uint(m));
+    sc.amax = 0.f;
+}
+
+__global__ __launch_bounds__(256) void canonical_bwd16_kernel(const float* __restrict__ xyz,
+                                                              const float4* __restrict__ d_raw,
+                                                              const uint32_t* __restrict__ relu_bits,
+                                                              const char* __restrict__ packed, int64_t P,
+                                                              const float* __restrict__ d_raw_amax,
+                                                              float* __restrict__ dZ, float* __restrict__ d_xyz,
+                                                              float* __restrict__ dz_amax) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    // slabs: head (16 blocks), then 32-block slabs; the first THREE are put in flight here (the head stage has
+    // only 8 k-steps to issue DMA pieces from, one short of a 32-block slab)
+    Pipe p = pipe_start(packed, 0, CNL16_BIAS_LDS, CNL16_SLAB, 16, 32, smem);
+    slab_issue(p.gi, p.lds_base + p.ring_off + 2 * CNL16_SLAB, 32, p.wave);
+    p.gi += 32 * 1024;
+    const int lane = threadIdx.x & 63, h = lane >> 5;
+    const int64_t slot = ((int64_t)blockIdx.x * 4 + p.wave) * 32 + (lane & 31);
+    const int64_t sample = slot < P ? slot : P - 1;            // lanes past P repeat sample P-1 (same values stored)
+    const int64_t stride = P * 256, bstride = P * 8;
+
+    int ex = 0;
+    const float am_in = *d_raw_amax;
+    if (am_in > 0.f) (void)frexpf(am_in, &ex);
+    const float scale = ldexpf(1.0f, 2 - ex);
+    const float4 g = d_raw[sample];
+    {
+        const float v[8] = {h ? 0.f : g.x * scale, h ? 0.f : g.y * scale, h ? 0.f : g.z * scale, h ? 0.f : g.w * scale,
+                            0.f, 0.f, 0.f, 0.f};
+        stash_pe(p, 0, v);
+    }
+    SaveCtx sc;
+    sc.descale = ldexpf(1.0f, ex - 2);
+    sc.amax = 0.f;
+    sc.row = dZ + 7 * stride + sample * 256 + 4 * h;
+    const uint32_t* mrow = relu_bits + 7 * bstride + sample * 8 + 4 * h;
+    float* am = dz_amax ? dz_amax + 7 * HNRF_AMAX_SLOTS + (blockIdx.x % HNRF_AMAX_SLOTS) : nullptr;
+    auto next_stage = [&]() {                                    // after a stored stage: publish its maximum, step a layer down
+        chain_amax(sc, am);
+        sc.row -= stride;
+        mrow -= bstride;
+        if (am) am -= HNRF_AMAX_SLOTS;
+    };
+    auto load_mask = [&]() {
+        const uint4 m = *reinterpret_cast<const uint4*>(mrow);
+        sc.mask[0] = m.x; sc.mask[1] = m.y; sc.mask[2] = m.z; sc.mask[3] = m.w;
+    };
+    tile_sync(0);
+
+    h16x8 hA_h[16], hA_l[16], hB_h[16], hB_l[16];
+    h16x8 dh[4], dl[4];
+    float last[16];
+    load_mask();
+    layer16<8, 8, 1, 0, false, 2>(p, 0, 0, hB_h, hB_l, hA_h, hA_l, last, &sc);                 // dZ7 (hB unused: NKB = 0)
+    next_stage();
+#pragma unroll 1
+    for (int m = 6; m >= 5; --m) {                                                             // dZ6, dZ5
+        load_mask();
+        layer16<8, 1, 0, 16, false, 2>(p, 32, 32, hA_h, hA_l, hB_h, hB_l, last, &sc);
+        next_stage();
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { hA_h[i] = hB_h[i]; hA_l[i] = hB_l[i]; }
+    }
+    load_mask();
+    layer16<8, 1, 0, 16, false, 2>(p, 32, 32, hA_h, hA_l, hB_h, hB_l, last, &sc);             // skip layer: dZ4 ...
+    next_stage();
+    layer16<2, 1, 0, 16, false, 3>(p, 32, 32, hA_h, hA_l, dh, dl, last, &sc);                 // ... and its d PE
+    float dpe[32];
+#pragma unroll
+    for (int j = 0; j < 32; ++j) dpe[j] = sc.fout[j];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { hA_h[i] = hB_h[i]; hA_l[i] = hB_l[i]; }
+#pragma unroll 1
+    for (int m = 3; m >= 0; --m) {                                                             // dZ3 .. dZ0
+        load_mask();
+        layer16<8, 1, 0, 16, false, 2>(p, 32, 32, hA_h, hA_l, hB_h, hB_l, last, &sc);
+        next_stage();
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { hA_h[i] = hB_h[i]; hA_l[i] = hB_l[i]; }
+    }
+    layer16<2, 1, 0, 16, false, 3>(p, 0, 0, hA_h, hA_l, dh, dl, last, &sc);                   // layer 0's d PE
+#pragma unroll
+    for (int j = 0; j < 32; ++j) dpe[j] = (dpe[j] + sc.fout[j]) * sc.descale;
+
+    // PE backward on the lane's own sample: argument a = 3 k + axis, half 0 = sin, half 1 = cos
+    const float x[3] = {xyz[sample * 3 + 0], xyz[sample * 3 + 1], xyz[sample * 3 + 2]};
+    float dx[3] = {0.f, 0.f, 0.f};
+    {
+        OctavePhase ph[3] = {OctavePhase(x[0]), OctavePhase(x[1]), OctavePhase(x[2])};
+#pragma unroll
+        for (int a = 0; a < 30; ++a) {
+            float sv, cv;
+            ph[a % 3].next(sv, cv);
+            const float f = (float)(1 << (a / 3));
+            dx[a % 3] += f * (h ? -sv : cv) * dpe[a];
+        }
+    }
+    dx[h ? 1 : 0] += dpe[30];
+    if (h == 0) dx[2] += dpe[31];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) dx[a] += __shfl_xor(dx[a], 32, 64);
+    if (h == 0 && slot < P) {
+        d_xyz[sample * 3 + 0] = dx[0];
+        d_xyz[sample * 3 + 1] = dx[1];
+        d_xyz[sample * 3 + 2] = dx[2];
     }
 }
 
@@ -783,6 +1017,43 @@ int nonrigid16_fwd_train(const float* x_skel, const float* hann_w, const void* p
     hipLaunchKernelGGL(nonrigid_f16x3_kernel<true>, dim3((unsigned)((P + 127) / 128)), dim3(256), lds, st, x_skel, hann_w,
                        (const char*)packed, P, xyz, offsets, nullptr, nullptr, pe_out, acts, relu_bits);
     return check_launch("hnrf_nonrigid_fwd_train (f16x3)");
+}
+
+size_t canonical16_bwd_bytes() { return (size_t)CB16_BYTES; }
+
+int canonical16_bwd_pack(const float* const* w, void* packed, hipStream_t st) {
+    char* out = (char*)packed;
+    auto launch = [&](const PackBwd16& d) {
+        const int64_t n = (int64_t)d.NT * 2 * d.NK * 256;
+        hipLaunchKernelGGL(pack_bwd16_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d, out);
+        return check_launch("hnrf pack (backward, f16x3)");
+    };
+    int rc;
+    if ((rc = launch(PackBwd16{w[8], 4, 256, 8, 1, PE16_NONE, 0, 1, CB16_HEAD}))) return rc;
+    for (int l = 7; l >= 6; --l)
+        if ((rc = launch(PackBwd16{w[l], 256, 256, 8, 16, PE16_NONE, 0, 0, CB16_L7 + (7 - l) * CB16_FULL}))) return rc;
+    if ((rc = launch(PackBwd16{w[5], 256, 319, 8, 16, PE16_NONE, 63, 0, CB16_L7 + 2 * CB16_FULL}))) return rc;
+    if ((rc = launch(PackBwd16{w[5], 256, 319, 2, 16, PE16_CANONICAL, 0, 0, CB16_L5P}))) return rc;
+    for (int l = 4; l >= 1; --l)
+        if ((rc = launch(PackBwd16{w[l], 256, 256, 8, 16, PE16_NONE, 0, 0, CB16_L4 + (4 - l) * CB16_FULL}))) return rc;
+    return launch(PackBwd16{w[0], 256, 63, 2, 16, PE16_CANONICAL, 0, 0, CB16_L0P});
+}
+
+int canonical16_bwd(const float* xyz, const float* d_raw, const uint32_t* relu_bits, const void* packed, int64_t P,
+                    const float* d_raw_amax, float* dZ, float* d_xyz, float* dz_amax, hipStream_t st) {
+    constexpr int lds = CNL16_BIAS_LDS + PE_STASH + RING * CNL16_SLAB;
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute((const void*)canonical_bwd16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds) !=
+            hipSuccess) {
+            set_error("hnrf_canonical_bwd (f16x3): cannot reserve %d bytes of LDS", lds);
+            return HNRF_E_LAUNCH;
+        }
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(canonical_bwd16_kernel, dim3((unsigned)((P + 127) / 128)), dim3(256), lds, st, xyz,
+                       (const float4*)d_raw, relu_bits, (const char*)packed, P, d_raw_amax, dZ, d_xyz, dz_amax);
+    return check_launch("hnrf_canonical_bwd (f16x3)");
 }
 
 }  // namespace hnrf

@@ -244,7 +244,7 @@ def pe_bwd(x, g, hann_w, n_bands, include_input, out=None):
     return out
 
 
-def canonical_bwd(xyz, d_raw, bits, weights):
+def canonical_bwd(xyz, d_raw, bits, weights, mode='f32'):
     """dX chain of the canonical MLP: returns dZ (8,P,256), d_xyz (P,3) and amax (8,64) (max over row l bounds
     |dZ_l|).  bits: sign masks from canonical_train."""
     lib = _lib.load()
@@ -252,13 +252,15 @@ def canonical_bwd(xyz, d_raw, bits, weights):
     P = xyz.numel() // 3
     assert bits.shape == (8, P, 8) and bits.dtype == torch.int32 and bits.is_contiguous()
     assert d_raw.numel() == 4 * P and len(weights) == 9
-    packed = torch.empty(lib.hnrf_canonical_bwd_packed_bytes() // 4, device=xyz.device)
-    _lib.check(lib.hnrf_canonical_bwd_pack(_ptr_array(weights), _ptr(packed), _stream()), 'hnrf_canonical_bwd_pack')
+    m = MLP_MODES[mode]
+    packed = torch.empty(lib.hnrf_canonical_bwd_packed_bytes(m) // 4, device=xyz.device)
+    _lib.check(lib.hnrf_canonical_bwd_pack(_ptr_array(weights), m, _ptr(packed), _stream()), 'hnrf_canonical_bwd_pack')
+    d_raw_amax = d_raw.abs().amax().reshape(1) if mode == 'f16x3' else None
     dZ = torch.empty(8, P, 256, device=xyz.device)
     d_xyz = torch.empty(P, 3, device=xyz.device)
     amax = torch.empty(8, 64, device=xyz.device)
-    _lib.check(lib.hnrf_canonical_bwd(_ptr(xyz), _ptr(d_raw), bits.data_ptr(), _ptr(packed), P, _ptr(dZ), _ptr(d_xyz),
-                                      _ptr(amax), _stream()), 'hnrf_canonical_bwd')
+    _lib.check(lib.hnrf_canonical_bwd(_ptr(xyz), _ptr(d_raw), bits.data_ptr(), _ptr(packed), m, _ptr(d_raw_amax), P,
+                                      _ptr(dZ), _ptr(d_xyz), _ptr(amax), _stream()), 'hnrf_canonical_bwd')
     return dZ, d_xyz, amax
 
 

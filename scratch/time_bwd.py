@@ -28,3 +28,7 @@ print('canonical bwd chain   %.3f ms' % t(lambda: ops.canonical_bwd(x, g, bits, 
 cp16 = ops.canonical_pack(cw, cb, 'f16x3')
 print('canonical fwd f16x3 (infer) %.3f ms' % t(lambda: ops.canonical(x, cp16, 'f16x3')))
 print('canonical fwd f16x3 (train) %.3f ms' % t(lambda: ops.canonical_train(x, cp16, 'f16x3')))
+print('canonical bwd chain f16x3 %.3f ms' % t(lambda: ops.canonical_bwd(x, g, bits, cw, 'f16x3')))
+dz32, dx32, am32 = ops.canonical_bwd(x, g * 1e-7, bits, cw, 'f32')
+dz16, dx16, am16 = ops.canonical_bwd(x, g * 1e-7, bits, cw, 'f16x3')
+print('f16x3 vs f32 chain at |d_raw| ~ 1e-7: dZ rel diff %.2e, d_xyz rel diff %.2e' % (float((dz16 - dz32).abs().max() / dz32.abs().max()), float((dx16 - dx32).abs().max() / dx32.abs().max())))

@@ -200,7 +200,7 @@ def test_canonical_backward_chain_and_weight_gradients_match_autograd(mode):
     T = lambda a: torch.from_numpy(a).to(dev())
     ws, bs = [T(st[n + '.weight']) for n in names], [T(st[n + '.bias']) for n in names]
     raw, pe, acts, bits = ops.canonical_train(T(xyz), ops.canonical_pack(ws, bs, mode), mode)
-    dZ, d_xyz, amax = ops.canonical_bwd(T(xyz), T(g_raw), bits, ws)
+    dZ, d_xyz, amax = ops.canonical_bwd(T(xyz), T(g_raw), bits, ws, mode)
     assert torch.equal(amax.amax(1), dZ.abs().amax(dim=(1, 2)))
     gW, gb = _weight_grads(dZ, acts, pe, T(g_raw), ws, skip_layer=5, skip_order='pe_first', amax=amax, mode=mode)
 
