@@ -232,7 +232,7 @@ def main():
         assert torch.isfinite(loss)
         result['train'] = {'iters_per_s': round(args.train_steps / tt, 3), 'ms_per_iter': round(tt / args.train_steps * 1e3, 2),
                            'steps': args.train_steps, 'rays_per_iter_per_gpu': int(idx.numel()), 'samples_per_ray': S,
-                           'frames_per_iter': world, 'mlp_arithmetic': 'forward, canonical dX chain and dW split-f16 MFMA (fp32-equivalent), non-rigid dX chain fp32 MFMA; no library GEMM on the per-sample path',
+                           'frames_per_iter': world, 'mlp_arithmetic': 'forward, dX chains and dW on split-f16 MFMA (fp32-equivalent; PE blocks and heads of dW fp32); no library GEMM on the per-sample path',
                            'loss': '0.2*MSE on rgb (LPIPS-VGG unavailable offline)',
                            'note': 'reference DataParallel trains 1 frame/iter at any GPU count; here N ranks = N frames/iter'}
         net.eval()

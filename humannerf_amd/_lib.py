@@ -35,11 +35,11 @@ SIGNATURES = {
     'hnrf_mlp_dw_workspace_bytes': (_sz, [_i64, _int, _int]),
     'hnrf_mlp_dw': (_int, [_vp, _i64, _vp, _i64, _i64, _int, _int, _int, _vp, _int, _vp, _i64, _vp, _vp, _sz, _vp]),
     'hnrf_canonical_bwd_packed_bytes': (_sz, [_int]),
-    'hnrf_nonrigid_bwd_packed_bytes': (_sz, []),
+    'hnrf_nonrigid_bwd_packed_bytes': (_sz, [_int]),
     'hnrf_canonical_bwd_pack': (_int, [_vp, _int, _vp, _vp]),
-    'hnrf_nonrigid_bwd_pack': (_int, [_vp, _vp, _vp]),
+    'hnrf_nonrigid_bwd_pack': (_int, [_vp, _int, _vp, _vp]),
     'hnrf_canonical_bwd': (_int, [_vp, _vp, _vp, _vp, _int, _vp, _i64, _vp, _vp, _vp, _vp]),
-    'hnrf_nonrigid_bwd': (_int, [_vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp]),
+    'hnrf_nonrigid_bwd': (_int, [_vp, _vp, _vp, _vp, _vp, _int, _vp, _i64, _vp, _vp, _vp, _vp]),
     'hnrf_gen_rays_workspace_bytes': (_sz, [_int, _int]),
     'hnrf_gen_rays': (_int, [_vp] * 5 + [_int, _int] + [_vp] * 7 + [_sz, _vp]),
     'hnrf_render_workspace_bytes': (_sz, [_i64, _int]),

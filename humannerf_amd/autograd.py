@@ -83,7 +83,8 @@ class RenderRays(torch.autograd.Function):
         del dZc
         if ctx.use_nonrigid:
             # xyz = x_skel + offset; layer 0 input [cond69 | PE36], skip layer 4 takes [h | PE36]
-            dZn, d_x_skel, amax_n = ops.nonrigid_bwd(x_skel.reshape(P, 3), hann_w, d_xyz, bits_n, nr_w)
+            dZn, d_x_skel, amax_n = ops.nonrigid_bwd(x_skel.reshape(P, 3), hann_w, d_xyz, bits_n, nr_w,
+                                                     amd_option('train_chain_mode', 'f16x3'))
             gWn, gbn = _weight_grads(dZn, acts_n, pe_n, d_xyz, nr_w, skip_layer=4, skip_order='h_first', amax=amax_n,
                                      mode=dw_mode)
             # condition-code columns of layer 0: the same vector for every sample

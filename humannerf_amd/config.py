@@ -122,7 +122,7 @@ _DEFAULTS = {
         'train_mlp_mode': 'f16x3',
         # arithmetic of the weight-gradient kernel for the matrix-shaped layers ('f32' | 'f16x3')
         'train_dw_mode': 'f16x3',
-        # arithmetic of the canonical MLP's dX chain ('f32' | 'f16x3'; the non-rigid chain is fp32 MFMA)
+        # arithmetic of the two dX chains ('f32' | 'f16x3')
         'train_chain_mode': 'f16x3',
         # materialise the per-sample diagnostic outputs the reference always
         # returns (backward_motion_weights, xyz_on_rays, ...; ~17 KB/ray).

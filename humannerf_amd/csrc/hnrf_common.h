@@ -48,4 +48,10 @@ int canonical16_bwd_pack(const float* const* w, void* packed, hipStream_t st);
 int canonical16_bwd(const float* xyz, const float* d_raw, const uint32_t* relu_bits, const void* packed, int64_t P,
                     const float* d_raw_amax, float* dZ, float* d_xyz, float* dz_amax, hipStream_t st);
 
+size_t nonrigid16_bwd_bytes();
+int nonrigid16_bwd_pack(const float* const* w, void* packed, hipStream_t st);
+int nonrigid16_bwd(const float* x_skel, const float* hann_w, const float* d_xyz, const uint32_t* relu_bits,
+                   const void* packed, int64_t P, const float* d_xyz_amax, float* dZ, float* d_x_skel, float* dz_amax,
+                   hipStream_t st);
+
 }  // namespace hnrf

@@ -778,7 +778,10 @@ extern "C" size_t hnrf_canonical_bwd_packed_bytes(int mode) {
     if (mode == HNRF_MLP_F16X3) return canonical16_bwd_bytes();
     return mode == HNRF_MLP_F32 ? (size_t)CB_FLOATS * sizeof(float) : 0;
 }
-extern "C" size_t hnrf_nonrigid_bwd_packed_bytes(void) { return (size_t)NB_FLOATS * sizeof(float); }
+extern "C" size_t hnrf_nonrigid_bwd_packed_bytes(int mode) {
+    if (mode == HNRF_MLP_F16X3) return nonrigid16_bwd_bytes();
+    return mode == HNRF_MLP_F32 ? (size_t)NB_FLOATS * sizeof(float) : 0;
+}
 
 extern "C" int hnrf_canonical_bwd_pack(const float* const* weights, int mode, void* packed, void* stream) {
     HNRF_REQUIRE(weights && packed, HNRF_E_ARG, "hnrf_canonical_bwd_pack: null pointer");
@@ -805,10 +808,13 @@ extern "C" int hnrf_canonical_bwd_pack(const float* const* weights, int mode, vo
     return launch_pack_bwd(PackBwd{weights[0], 256, 63, 2, 32, PE_CANONICAL, 0, 0, CB_L0P}, out, st);
 }
 
-extern "C" int hnrf_nonrigid_bwd_pack(const float* const* weights, void* packed, void* stream) {
+extern "C" int hnrf_nonrigid_bwd_pack(const float* const* weights, int mode, void* packed, void* stream) {
     HNRF_REQUIRE(weights && packed, HNRF_E_ARG, "hnrf_nonrigid_bwd_pack: null pointer");
+    HNRF_REQUIRE(mode == HNRF_MLP_F32 || mode == HNRF_MLP_F16X3, HNRF_E_UNSUPPORTED,
+                 "hnrf_nonrigid_bwd_pack: mode %d not built", mode);
     for (int i = 0; i < 7; ++i) HNRF_REQUIRE(weights[i], HNRF_E_ARG, "hnrf_nonrigid_bwd_pack: null layer %d", i);
     hipStream_t st = (hipStream_t)stream;
+    if (mode == HNRF_MLP_F16X3) return nonrigid16_bwd_pack(weights, packed, st);
     float* out = (float*)packed;
     if (hipMemsetAsync(out + NB_END, 0, PF * 256 * sizeof(float), st) != hipSuccess) {
         set_error("hnrf_nonrigid_bwd_pack: memset failed");
@@ -851,8 +857,12 @@ extern "C" int hnrf_canonical_bwd(const float* xyz, const float* d_raw, const ui
 }
 
 extern "C" int hnrf_nonrigid_bwd(const float* x_skel, const float* hann_w, const float* d_xyz,
-                                 const uint32_t* relu_bits, const void* packed, int64_t P, float* dZ,
-                                 float* d_x_skel, float* dz_amax, void* stream) {
+                                 const uint32_t* relu_bits, const void* packed, int mode,
+                                 const float* d_xyz_amax, int64_t P, float* dZ, float* d_x_skel, float* dz_amax,
+                                 void* stream) {
+    HNRF_REQUIRE(mode == HNRF_MLP_F32 || mode == HNRF_MLP_F16X3, HNRF_E_UNSUPPORTED, "hnrf_nonrigid_bwd: mode %d not built", mode);
+    HNRF_REQUIRE(mode != HNRF_MLP_F16X3 || d_xyz_amax, HNRF_E_ARG,
+                 "hnrf_nonrigid_bwd: HNRF_MLP_F16X3 needs d_xyz_amax (device scalar >= max |d_xyz|)");
     HNRF_REQUIRE(x_skel && hann_w && d_xyz && relu_bits && packed && dZ && d_x_skel, HNRF_E_ARG,
                  "hnrf_nonrigid_bwd: null pointer");
     HNRF_REQUIRE(P >= 0, HNRF_E_ARG, "hnrf_nonrigid_bwd: bad P");
@@ -865,6 +875,9 @@ extern "C" int hnrf_nonrigid_bwd(const float* x_skel, const float* hann_w, const
         set_error("hnrf_nonrigid_bwd: memset failed");
         return HNRF_E_LAUNCH;
     }
+    if (mode == HNRF_MLP_F16X3)
+        return nonrigid16_bwd(x_skel, hann_w, d_xyz, relu_bits, packed, P, d_xyz_amax, dZ, d_x_skel, dz_amax,
+                              (hipStream_t)stream);
     hipLaunchKernelGGL(nonrigid_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x_skel, hann_w,
                        d_xyz, relu_bits, (const float*)packed, P, dZ, d_x_skel, dz_amax);
     return check_launch("hnrf_nonrigid_bwd");

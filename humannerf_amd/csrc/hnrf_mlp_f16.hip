@@ -894,6 +894,115 @@ __global__ __launch_bounds__(256) void canonical_bwd16_kernel(const float* __res
     }
 }
 
+// image of the non-rigid chain: head (4 tiles x 2 blocks) | W5^T (4 x 16) | W4^T hidden rows (4 x 16) |
+//   W4^T PE rows (2 x 16) | W3^T W2^T W1^T (4 x 16 each) | W0^T PE rows (2 x 16); slabs of 32 blocks after the head
+constexpr int64_t NB16_HEAD = 0;
+constexpr int64_t NB16_FULL = 4 * 16 * KB;
+constexpr int64_t NB16_PE = 2 * 16 * KB;
+constexpr int64_t NB16_L5 = NB16_HEAD + 8 * KB;
+constexpr int64_t NB16_L4P = NB16_L5 + 2 * NB16_FULL;
+constexpr int64_t NB16_L3 = NB16_L4P + NB16_PE;
+constexpr int64_t NB16_L0P = NB16_L3 + 3 * NB16_FULL;
+constexpr int64_t NB16_BYTES = NB16_L0P + NB16_PE;
+
+// Non-rigid MLP, split-f16 (xyz = x_skel + offset): d_x_skel = d_xyz + J_offset^T d_xyz, dZ [6][P][128].
+__global__ __launch_bounds__(256) void nonrigid_bwd16_kernel(const float* __restrict__ x_skel,
+                                                             const float* __restrict__ hann_w,
+                                                             const float* __restrict__ d_xyz,
+                                                             const uint32_t* __restrict__ relu_bits,
+                                                             const char* __restrict__ packed, int64_t P,
+                                                             const float* __restrict__ d_xyz_amax,
+                                                             float* __restrict__ dZ, float* __restrict__ d_x_skel,
+                                                             float* __restrict__ dz_amax) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    Pipe p = pipe_start(packed, 0, NR16_BIAS_LDS, NR16_SLAB, 8, 32, smem);
+    slab_issue(p.gi, p.lds_base + p.ring_off + 2 * NR16_SLAB, 32, p.wave);      // third slab: see canonical_bwd16_kernel
+    p.gi += 32 * 1024;
+    const int lane = threadIdx.x & 63, h = lane >> 5;
+    const int64_t slot = ((int64_t)blockIdx.x * 4 + p.wave) * 32 + (lane & 31);
+    const int64_t sample = slot < P ? slot : P - 1;
+    const int64_t stride = P * 128, bstride = P * 4;
+
+    int ex = 0;
+    const float am_in = *d_xyz_amax;
+    if (am_in > 0.f) (void)frexpf(am_in, &ex);
+    const float scale = ldexpf(1.0f, 2 - ex);
+    const float g[3] = {d_xyz[sample * 3 + 0], d_xyz[sample * 3 + 1], d_xyz[sample * 3 + 2]};
+    {
+        const float v[8] = {h ? 0.f : g[0] * scale, h ? 0.f : g[1] * scale, h ? 0.f : g[2] * scale, 0.f, 0.f, 0.f, 0.f, 0.f};
+        stash_pe(p, 0, v);
+    }
+    SaveCtx sc;
+    sc.descale = ldexpf(1.0f, ex - 2);
+    sc.amax = 0.f;
+    sc.mask[2] = sc.mask[3] = 0u;
+    sc.row = dZ + 5 * stride + sample * 128 + 4 * h;
+    const uint32_t* mrow = relu_bits + 5 * bstride + sample * 4 + 2 * h;
+    float* am = dz_amax ? dz_amax + 5 * HNRF_AMAX_SLOTS + (blockIdx.x % HNRF_AMAX_SLOTS) : nullptr;
+    auto next_stage = [&]() {
+        chain_amax(sc, am);
+        sc.row -= stride;
+        mrow -= bstride;
+        if (am) am -= HNRF_AMAX_SLOTS;
+    };
+    auto load_mask = [&]() {
+        const uint2 m = *reinterpret_cast<const uint2*>(mrow);
+        sc.mask[0] = m.x; sc.mask[1] = m.y;
+    };
+    tile_sync(0);
+
+    h16x8 hA_h[8], hA_l[8], hB_h[8], hB_l[8];
+    h16x8 dh[4], dl[4];
+    float last[16];
+    load_mask();
+    layer16<4, 4, 1, 0, false, 2>(p, 0, 0, hB_h, hB_l, hA_h, hA_l, last, &sc);                // dZ5
+    next_stage();
+    load_mask();
+    layer16<4, 2, 0, 8, false, 2>(p, 32, 32, hA_h, hA_l, hB_h, hB_l, last, &sc);             // dZ4 (the skip layer's)
+    next_stage();
+    load_mask();
+    layer16<4, 2, 0, 8, false, 2>(p, 32, 32, hB_h, hB_l, hA_h, hA_l, last, &sc);             // skip [h | PE]: dZ3 ...
+    next_stage();
+    layer16<2, 2, 0, 8, false, 3>(p, 32, 32, hB_h, hB_l, dh, dl, last, &sc);                 // ... and its d PE
+    float dpe[18];
+#pragma unroll
+    for (int j = 0; j < 18; ++j) dpe[j] = sc.fout[j];
+#pragma unroll 1
+    for (int m = 2; m >= 1; --m) {                                                            // dZ2, dZ1
+        load_mask();
+        layer16<4, 2, 0, 8, false, 2>(p, 32, 32, hA_h, hA_l, hB_h, hB_l, last, &sc);
+        next_stage();
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { hA_h[i] = hB_h[i]; hA_l[i] = hB_l[i]; }
+    }
+    load_mask();
+    layer16<4, 2, 0, 8, false, 2>(p, 32, 0, hA_h, hA_l, hB_h, hB_l, last, &sc);              // dZ0
+    next_stage();
+    layer16<2, 2, 0, 8, false, 3>(p, 0, 0, hB_h, hB_l, dh, dl, last, &sc);                   // layer 0's d PE
+#pragma unroll
+    for (int j = 0; j < 18; ++j) dpe[j] = (dpe[j] + sc.fout[j]) * sc.descale;
+
+    const float x[3] = {x_skel[sample * 3 + 0], x_skel[sample * 3 + 1], x_skel[sample * 3 + 2]};
+    float dx[3] = {0.f, 0.f, 0.f};
+    {
+        OctavePhase ph[3] = {OctavePhase(x[0]), OctavePhase(x[1]), OctavePhase(x[2])};
+#pragma unroll
+        for (int a = 0; a < 18; ++a) {
+            float sv, cv;
+            ph[a % 3].next(sv, cv);
+            const float f = hann_w[a / 3] * (float)(1 << (a / 3));
+            dx[a % 3] += f * (h ? -sv : cv) * dpe[a];
+        }
+    }
+#pragma unroll
+    for (int a = 0; a < 3; ++a) dx[a] += __shfl_xor(dx[a], 32, 64);
+    if (h == 0 && slot < P) {
+        d_x_skel[sample * 3 + 0] = g[0] + dx[0];
+        d_x_skel[sample * 3 + 1] = g[1] + dx[1];
+        d_x_skel[sample * 3 + 2] = g[2] + dx[2];
+    }
+}
+
 static int launch_pack16(const PackLayer16& d, const float* cond, char* packed, hipStream_t st) {
     const int64_t n = (int64_t)d.NT * (2 * (d.NKA + d.NKB) * 256);
     hipLaunchKernelGGL(pack_layer16_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d, cond, packed);
@@ -1054,6 +1163,43 @@ int canonical16_bwd(const float* xyz, const float* d_raw, const uint32_t* relu_b
     hipLaunchKernelGGL(canonical_bwd16_kernel, dim3((unsigned)((P + 127) / 128)), dim3(256), lds, st, xyz,
                        (const float4*)d_raw, relu_bits, (const char*)packed, P, d_raw_amax, dZ, d_xyz, dz_amax);
     return check_launch("hnrf_canonical_bwd (f16x3)");
+}
+
+size_t nonrigid16_bwd_bytes() { return (size_t)NB16_BYTES; }
+
+int nonrigid16_bwd_pack(const float* const* w, void* packed, hipStream_t st) {
+    char* out = (char*)packed;
+    auto launch = [&](const PackBwd16& d) {
+        const int64_t n = (int64_t)d.NT * 2 * d.NK * 256;
+        hipLaunchKernelGGL(pack_bwd16_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d, out);
+        return check_launch("hnrf pack (backward, f16x3)");
+    };
+    int rc;
+    if ((rc = launch(PackBwd16{w[6], 3, 128, 4, 1, PE16_NONE, 0, 1, NB16_HEAD}))) return rc;
+    if ((rc = launch(PackBwd16{w[5], 128, 128, 4, 8, PE16_NONE, 0, 0, NB16_L5}))) return rc;
+    if ((rc = launch(PackBwd16{w[4], 128, 164, 4, 8, PE16_NONE, 0, 0, NB16_L5 + NB16_FULL}))) return rc;
+    if ((rc = launch(PackBwd16{w[4], 128, 164, 2, 8, PE16_NONRIGID, 128, 0, NB16_L4P}))) return rc;
+    for (int l = 3; l >= 1; --l)
+        if ((rc = launch(PackBwd16{w[l], 128, 128, 4, 8, PE16_NONE, 0, 0, NB16_L3 + (3 - l) * NB16_FULL}))) return rc;
+    return launch(PackBwd16{w[0], 128, 105, 2, 8, PE16_NONRIGID, 69, 0, NB16_L0P});
+}
+
+int nonrigid16_bwd(const float* x_skel, const float* hann_w, const float* d_xyz, const uint32_t* relu_bits,
+                   const void* packed, int64_t P, const float* d_xyz_amax, float* dZ, float* d_x_skel, float* dz_amax,
+                   hipStream_t st) {
+    constexpr int lds = NR16_BIAS_LDS + PE_STASH + RING * NR16_SLAB;
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute((const void*)nonrigid_bwd16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds) !=
+            hipSuccess) {
+            set_error("hnrf_nonrigid_bwd (f16x3): cannot reserve %d bytes of LDS", lds);
+            return HNRF_E_LAUNCH;
+        }
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(nonrigid_bwd16_kernel, dim3((unsigned)((P + 127) / 128)), dim3(256), lds, st, x_skel, hann_w, d_xyz,
+                       relu_bits, (const char*)packed, P, d_xyz_amax, dZ, d_x_skel, dz_amax);
+    return check_launch("hnrf_nonrigid_bwd (f16x3)");
 }
 
 }  // namespace hnrf

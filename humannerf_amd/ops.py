@@ -264,20 +264,22 @@ def canonical_bwd(xyz, d_raw, bits, weights, mode='f32'):
     return dZ, d_xyz, amax
 
 
-def nonrigid_bwd(x_skel, hann_w, d_xyz, bits, weights):
+def nonrigid_bwd(x_skel, hann_w, d_xyz, bits, weights, mode='f32'):
     """dX chain of the non-rigid MLP: returns dZ (6,P,128), d_x_skel (P,3) (identity path included), amax (6,64)."""
     lib = _lib.load()
     _chk(x_skel, hann_w, d_xyz, *weights)
     P = x_skel.numel() // 3
     assert bits.shape == (6, P, 4) and bits.dtype == torch.int32 and bits.is_contiguous()
     assert d_xyz.numel() == 3 * P and len(weights) == 7
-    packed = torch.empty(lib.hnrf_nonrigid_bwd_packed_bytes() // 4, device=x_skel.device)
-    _lib.check(lib.hnrf_nonrigid_bwd_pack(_ptr_array(weights), _ptr(packed), _stream()), 'hnrf_nonrigid_bwd_pack')
+    m = MLP_MODES[mode]
+    packed = torch.empty(lib.hnrf_nonrigid_bwd_packed_bytes(m) // 4, device=x_skel.device)
+    _lib.check(lib.hnrf_nonrigid_bwd_pack(_ptr_array(weights), m, _ptr(packed), _stream()), 'hnrf_nonrigid_bwd_pack')
+    d_amax = d_xyz.abs().amax().reshape(1) if mode == 'f16x3' else None
     dZ = torch.empty(6, P, 128, device=x_skel.device)
     d_x_skel = torch.empty(P, 3, device=x_skel.device)
     amax = torch.empty(6, 64, device=x_skel.device)
-    _lib.check(lib.hnrf_nonrigid_bwd(_ptr(x_skel), _ptr(hann_w), _ptr(d_xyz), bits.data_ptr(), _ptr(packed), P, _ptr(dZ),
-                                     _ptr(d_x_skel), _ptr(amax), _stream()), 'hnrf_nonrigid_bwd')
+    _lib.check(lib.hnrf_nonrigid_bwd(_ptr(x_skel), _ptr(hann_w), _ptr(d_xyz), bits.data_ptr(), _ptr(packed), m,
+                                     _ptr(d_amax), P, _ptr(dZ), _ptr(d_x_skel), _ptr(amax), _stream()), 'hnrf_nonrigid_bwd')
     return dZ, d_x_skel, amax
 
 

@@ -215,19 +215,20 @@ int hnrf_mlp_dw(const float* dZ, int64_t ldz, const float* X, int64_t ldx, int64
  *  non-rigid: x_skel [P,3], hann_w [6], d_xyz [P,3], relu_bits [6][P][4] from hnrf_nonrigid_fwd_train ->
  *    dZ [6][P][128] and d_x_skel [P,3] = d_xyz + J_offset^T d_xyz  (xyz = x_skel + offset, network.py:518-530). */
 size_t hnrf_canonical_bwd_packed_bytes(int mode);
-size_t hnrf_nonrigid_bwd_packed_bytes(void);
+size_t hnrf_nonrigid_bwd_packed_bytes(int mode);
 int hnrf_canonical_bwd_pack(const float* const* weights, int mode, void* packed, void* stream);
-int hnrf_nonrigid_bwd_pack(const float* const* weights, void* packed, void* stream);
+int hnrf_nonrigid_bwd_pack(const float* const* weights, int mode, void* packed, void* stream);
 /* dz_amax (nullable): [L][HNRF_AMAX_SLOTS] floats; max over row l bounds |dZ_l| (the scale input of
  * hnrf_mlp_dw in HNRF_MLP_F16X3 mode). */
 #define HNRF_AMAX_SLOTS 64
-/* mode HNRF_MLP_F16X3 (canonical only): the chain on the split-f16 matrix pipe; d_raw_amax = device scalar
- * >= max |d_raw| (sets the power-of-two scale of the gradients), ignored in HNRF_MLP_F32. */
+/* mode HNRF_MLP_F16X3: the chain on the split-f16 matrix pipe; d_raw_amax / d_xyz_amax = device scalar >= the
+ * largest magnitude of the incoming gradient (sets its power-of-two scale), ignored in HNRF_MLP_F32. */
 int hnrf_canonical_bwd(const float* xyz, const float* d_raw, const uint32_t* relu_bits, const void* packed,
                        int mode, const float* d_raw_amax, int64_t P, float* dZ, float* d_xyz, float* dz_amax,
                        void* stream);
 int hnrf_nonrigid_bwd(const float* x_skel, const float* hann_w, const float* d_xyz, const uint32_t* relu_bits,
-                      const void* packed, int64_t P, float* dZ, float* d_x_skel, float* dz_amax, void* stream);
+                      const void* packed, int mode, const float* d_xyz_amax, int64_t P, float* dZ, float* d_x_skel,
+                      float* dz_amax, void* stream);
 
 /* =============================== in front of the path ===============================
  * Ray generation + bbox intersection + order-preserving compaction (get_rays_from_KRT,

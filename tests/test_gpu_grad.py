@@ -236,7 +236,7 @@ def test_nonrigid_backward_chain_and_weight_gradients_match_autograd(mode):
     T = lambda a: torch.from_numpy(a).to(dev())
     ws, bs = [T(st[n + '.weight']) for n in names], [T(st[n + '.bias']) for n in names]
     xyz, off, pe, acts, bits = ops.nonrigid_train(T(x), T(hann), ops.nonrigid_pack(ws, bs, T(cond), mode), mode)
-    dZ, d_x, amax = ops.nonrigid_bwd(T(x), T(hann), T(g_xyz), bits, ws)
+    dZ, d_x, amax = ops.nonrigid_bwd(T(x), T(hann), T(g_xyz), bits, ws, mode)
     assert torch.equal(amax.amax(1), dZ.abs().amax(dim=(1, 2)))
     gW, gb = _weight_grads(dZ, acts, pe, T(g_xyz), ws, skip_layer=4, skip_order='h_first', amax=amax, mode=mode)
     gW[0] = torch.cat([gb[0][:, None] * T(cond).reshape(1, -1), gW[0]], dim=1)
