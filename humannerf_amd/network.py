@@ -20,6 +20,7 @@ in PyTorch-ROCm.
 Only the default-config branches are implemented; anything else raises.
 """
 import math
+import weakref
 
 import torch
 import torch.nn as nn
@@ -249,7 +250,9 @@ def motion_basis(dst_Rs, dst_Ts, cnl_gtfms):
     chain = [G[0]]
     for i in range(1, B):
         chain.append(torch.matmul(chain[SMPL_PARENT[i]], G[i]))
-    f_mtx = torch.matmul(cnl_gtfms, torch.inverse(torch.stack(chain)))
+    # inv_ex without the error check: torch.inverse reads the LAPACK status back to the host, a device
+    # synchronisation per frame that exposes the launch latency of everything queued behind it
+    f_mtx = torch.matmul(cnl_gtfms, torch.linalg.inv_ex(torch.stack(chain), check_errors=False).inverse)
     return f_mtx[:, :3, :3].contiguous(), f_mtx[:, :3, 3].contiguous()
 
 
@@ -331,11 +334,16 @@ class Network(nn.Module):
         use_cache = (not self.training) and (not torch.is_grad_enabled()) and amd_option('cache_weight_volume', True)
         key = _versions(params)
         if use_cache and self._vol_cache is not None and self._vol_cache[0] == key \
-                and self._vol_cache[1].shape == priors.shape and torch.equal(self._vol_cache[1], priors):
-            return self._vol_cache[2]
+                and self._vol_cache[1].shape == priors.shape:
+            # same tensor object as last frame (a driver that keeps the priors resident): no comparison, no host
+            # synchronisation; a fresh tensor is compared by value (one device round trip per frame)
+            ref, ver = self._vol_cache[3]
+            same = (ref() is priors and ver == priors._version) or torch.equal(self._vol_cache[1], priors)
+            if same:
+                return self._vol_cache[2]
         vol = self.mweight_vol_decoder(motion_weights_priors=priors[None])[0].contiguous()
         if use_cache:
-            self._vol_cache = (key, priors.clone(), vol)
+            self._vol_cache = (key, priors.clone(), vol, (weakref.ref(priors), priors._version))
         return vol
 
     # forward -------------------------------------------------------------------

@@ -52,6 +52,7 @@ def render_frames(network, frames, rank=0, world=1, device=None, on_image=None):
     out = {}
     copy_stream = torch.cuda.Stream(device=device) if device.type == 'cuda' else None
     pending = []
+    resident = {}                                                        # key -> (host array, device tensor)
     try:
         for idx in hdist.frame_shard(len(frames), rank, world):
             fr = frames[idx]
@@ -61,7 +62,18 @@ def render_frames(network, frames, rank=0, world=1, device=None, on_image=None):
                 fr.update(ops.gen_rays(fr['K'], fr['E'], fr['cnl_bbox_min_xyz'], fr['cnl_bbox_max_xyz'],
                                        int(fr['img_height']), int(fr['img_width']), device=device))
             data = {k: torch.as_tensor(np.ascontiguousarray(fr[k]) if isinstance(fr[k], np.ndarray) else fr[k]).to(device)
-                    for k in keys}
+                    for k in keys if k != 'motion_weights_priors'}
+            # the priors are per-subject constants: keep them on the device while the host copy is unchanged, so
+            # that the network's weight-volume cache hits by identity (no per-frame comparison / synchronisation)
+            pri = fr['motion_weights_priors']
+            hit = resident.get('priors')
+            if hit is not None and (hit[0] is pri or (isinstance(pri, np.ndarray) and isinstance(hit[0], np.ndarray)
+                                                      and hit[0].shape == pri.shape and np.array_equal(hit[0], pri))):
+                data['motion_weights_priors'] = hit[1]
+            else:
+                data['motion_weights_priors'] = torch.as_tensor(
+                    np.ascontiguousarray(pri) if isinstance(pri, np.ndarray) else pri).to(device)
+                resident['priors'] = (pri, data['motion_weights_priors'])
             with torch.no_grad():
                 res = network(**data, iter_val=float(cfg.eval_iter))
             mask = torch.as_tensor(fr['ray_mask']).to(device)
