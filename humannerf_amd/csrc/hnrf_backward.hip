@@ -314,15 +314,9 @@ extern "C" int hnrf_sample_warp_bwd(const float* rays_o, const float* rays_d, co
     const size_t lds = (size_t)G * G * G * sizeof(float);
     if (lds + 256 <= 160 * 1024 && P >= 65536) {
         // one 128-KiB LDS grid per block -> 1 block per CU; ~2 waves of blocks over the chip
-        static bool attr_set = false;
-        if (!attr_set) {
-            if (hipFuncSetAttribute((const void*)sample_warp_bwd_kernel<true>,
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) != hipSuccess) {
-                set_error("hnrf_sample_warp_bwd: cannot reserve LDS");
-                return HNRF_E_LAUNCH;
-            }
-            attr_set = true;
-        }
+        static unsigned long long lds_done = 0;
+        if (int rc = reserve_lds((const void*)sample_warp_bwd_kernel<true>, 150 * 1024, lds_done, "hnrf_sample_warp_bwd"))
+            return rc;
         int64_t bx = 512 / B;                        // blocks per bone
         if (bx < 1) bx = 1;
         if (bx > blocks) bx = blocks;

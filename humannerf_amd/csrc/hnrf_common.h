@@ -28,6 +28,21 @@ static inline int check_launch(const char* what) {
 
 constexpr int kWave = 64;
 
+// Opt a kernel into > 64 KiB of dynamic LDS, once per device of this process (`done`: one bit per device id;
+// the attribute is per device, and a process may drive more than one).
+static inline int reserve_lds(const void* fn, int bytes, unsigned long long& done, const char* what) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (done & bit) return HNRF_OK;
+    if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess) {
+        set_error("%s: cannot reserve %d bytes of LDS", what, bytes);
+        return HNRF_E_LAUNCH;
+    }
+    done |= bit;
+    return HNRF_OK;
+}
+
 // HNRF_MLP_F16X3 back end (hnrf_mlp_f16.hip)
 size_t canonical16_bytes();
 size_t nonrigid16_bytes();

@@ -1063,15 +1063,8 @@ int nonrigid16_pack(const float* const* w, const float* const* b, const float* c
 int canonical16_fwd(const float* xyz, const void* packed, int64_t P, float* raw, const int* idx, const int* count,
                     hipStream_t st) {
     constexpr int lds = CNL16_BIAS_LDS + PE_STASH + RING * CNL16_SLAB;
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute((const void*)canonical_f16x3_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                lds) != hipSuccess) {
-            set_error("hnrf_canonical_fwd (f16x3): cannot reserve %d bytes of LDS", lds);
-            return HNRF_E_LAUNCH;
-        }
-        attr_set = true;
-    }
+    static unsigned long long lds_done = 0;
+    if (int rc = reserve_lds((const void*)canonical_f16x3_kernel<false>, lds, lds_done, "hnrf_canonical_fwd (f16x3)")) return rc;
     hipLaunchKernelGGL(canonical_f16x3_kernel<false>, dim3((unsigned)((P + 127) / 128)), dim3(256), lds, st, xyz,
                        (const char*)packed, P, (float4*)raw, idx, count, nullptr, nullptr, nullptr);
     return check_launch("hnrf_canonical_fwd (f16x3)");
@@ -1080,15 +1073,8 @@ int canonical16_fwd(const float* xyz, const void* packed, int64_t P, float* raw,
 int canonical16_fwd_train(const float* xyz, const void* packed, int64_t P, float* raw, float* pe_out, float* acts,
                           uint32_t* relu_bits, hipStream_t st) {
     constexpr int lds = CNL16_BIAS_LDS + PE_STASH + RING * CNL16_SLAB;
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute((const void*)canonical_f16x3_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                lds) != hipSuccess) {
-            set_error("hnrf_canonical_fwd_train (f16x3): cannot reserve %d bytes of LDS", lds);
-            return HNRF_E_LAUNCH;
-        }
-        attr_set = true;
-    }
+    static unsigned long long lds_done = 0;
+    if (int rc = reserve_lds((const void*)canonical_f16x3_kernel<true>, lds, lds_done, "hnrf_canonical_fwd_train (f16x3)")) return rc;
     hipLaunchKernelGGL(canonical_f16x3_kernel<true>, dim3((unsigned)((P + 127) / 128)), dim3(256), lds, st, xyz,
                        (const char*)packed, P, (float4*)raw, nullptr, nullptr, pe_out, acts, relu_bits);
     return check_launch("hnrf_canonical_fwd_train (f16x3)");
@@ -1097,15 +1083,8 @@ int canonical16_fwd_train(const float* xyz, const void* packed, int64_t P, float
 int nonrigid16_fwd(const float* x_skel, const float* hann_w, const void* packed, int64_t P, float* xyz,
                    float* offsets, const int* idx, const int* count, hipStream_t st) {
     constexpr int lds = NR16_BIAS_LDS + PE_STASH + RING * NR16_SLAB;
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute((const void*)nonrigid_f16x3_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                lds) != hipSuccess) {
-            set_error("hnrf_nonrigid_fwd (f16x3): cannot reserve %d bytes of LDS", lds);
-            return HNRF_E_LAUNCH;
-        }
-        attr_set = true;
-    }
+    static unsigned long long lds_done = 0;
+    if (int rc = reserve_lds((const void*)nonrigid_f16x3_kernel<false>, lds, lds_done, "hnrf_nonrigid_fwd (f16x3)")) return rc;
     hipLaunchKernelGGL(nonrigid_f16x3_kernel<false>, dim3((unsigned)((P + 127) / 128)), dim3(256), lds, st, x_skel, hann_w,
                        (const char*)packed, P, xyz, offsets, idx, count, nullptr, nullptr, nullptr);
     return check_launch("hnrf_nonrigid_fwd (f16x3)");
@@ -1114,15 +1093,8 @@ int nonrigid16_fwd(const float* x_skel, const float* hann_w, const void* packed,
 int nonrigid16_fwd_train(const float* x_skel, const float* hann_w, const void* packed, int64_t P, float* xyz,
                          float* offsets, float* pe_out, float* acts, uint32_t* relu_bits, hipStream_t st) {
     constexpr int lds = NR16_BIAS_LDS + PE_STASH + RING * NR16_SLAB;
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute((const void*)nonrigid_f16x3_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                lds) != hipSuccess) {
-            set_error("hnrf_nonrigid_fwd_train (f16x3): cannot reserve %d bytes of LDS", lds);
-            return HNRF_E_LAUNCH;
-        }
-        attr_set = true;
-    }
+    static unsigned long long lds_done = 0;
+    if (int rc = reserve_lds((const void*)nonrigid_f16x3_kernel<true>, lds, lds_done, "hnrf_nonrigid_fwd_train (f16x3)")) return rc;
     hipLaunchKernelGGL(nonrigid_f16x3_kernel<true>, dim3((unsigned)((P + 127) / 128)), dim3(256), lds, st, x_skel, hann_w,
                        (const char*)packed, P, xyz, offsets, nullptr, nullptr, pe_out, acts, relu_bits);
     return check_launch("hnrf_nonrigid_fwd_train (f16x3)");
@@ -1151,15 +1123,8 @@ int canonical16_bwd_pack(const float* const* w, void* packed, hipStream_t st) {
 int canonical16_bwd(const float* xyz, const float* d_raw, const uint32_t* relu_bits, const void* packed, int64_t P,
                     const float* d_raw_amax, float* dZ, float* d_xyz, float* dz_amax, hipStream_t st) {
     constexpr int lds = CNL16_BIAS_LDS + PE_STASH + RING * CNL16_SLAB;
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute((const void*)canonical_bwd16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds) !=
-            hipSuccess) {
-            set_error("hnrf_canonical_bwd (f16x3): cannot reserve %d bytes of LDS", lds);
-            return HNRF_E_LAUNCH;
-        }
-        attr_set = true;
-    }
+    static unsigned long long lds_done = 0;
+    if (int rc = reserve_lds((const void*)canonical_bwd16_kernel, lds, lds_done, "hnrf_canonical_bwd (f16x3)")) return rc;
     hipLaunchKernelGGL(canonical_bwd16_kernel, dim3((unsigned)((P + 127) / 128)), dim3(256), lds, st, xyz,
                        (const float4*)d_raw, relu_bits, (const char*)packed, P, d_raw_amax, dZ, d_xyz, dz_amax);
     return check_launch("hnrf_canonical_bwd (f16x3)");
@@ -1188,15 +1153,8 @@ int nonrigid16_bwd(const float* x_skel, const float* hann_w, const float* d_xyz,
                    const void* packed, int64_t P, const float* d_xyz_amax, float* dZ, float* d_x_skel, float* dz_amax,
                    hipStream_t st) {
     constexpr int lds = NR16_BIAS_LDS + PE_STASH + RING * NR16_SLAB;
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute((const void*)nonrigid_bwd16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds) !=
-            hipSuccess) {
-            set_error("hnrf_nonrigid_bwd (f16x3): cannot reserve %d bytes of LDS", lds);
-            return HNRF_E_LAUNCH;
-        }
-        attr_set = true;
-    }
+    static unsigned long long lds_done = 0;
+    if (int rc = reserve_lds((const void*)nonrigid_bwd16_kernel, lds, lds_done, "hnrf_nonrigid_bwd (f16x3)")) return rc;
     hipLaunchKernelGGL(nonrigid_bwd16_kernel, dim3((unsigned)((P + 127) / 128)), dim3(256), lds, st, x_skel, hann_w, d_xyz,
                        relu_bits, (const char*)packed, P, d_xyz_amax, dZ, d_x_skel, dz_amax);
     return check_launch("hnrf_nonrigid_bwd (f16x3)");

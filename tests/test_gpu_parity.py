@@ -419,3 +419,37 @@ def test_ray_generation_kernel(H, W, focal):
     np.testing.assert_allclose(got['far'][:, 0].cpu().numpy(), far.astype(np.float32), rtol=2e-6, atol=2e-6)
     if focal < 1700.0:
         assert 0 < hit.sum() < H * W                          # the compaction really dropped pixels
+
+
+def test_c5_full_frame_is_chunk_and_neighbour_independent(seeded_params):
+    """BASELINE config 5 at full size (1024 x 1024 rays x 256 samples = 268 M samples, rays generated on the
+    device): every 4099-th ray rendered alone gives bit-identical rgb / alpha / depth -- a ray's result does not
+    depend on which chunk it travels in or on its neighbours (size-independent property of the path)."""
+    from humannerf_amd import ops, scene
+    from humannerf_amd.config import cfg
+    from humannerf_amd.network import Network
+    d = dev()
+    net = Network()
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in seeded_params.items()})
+    net = net.to(d).eval()
+    fr = scene.synthetic_frame(H=1024, W=1024, focal_at_512=1700.0, camera_only=True)
+    rays = ops.gen_rays(fr['K'], fr['E'], fr['cnl_bbox_min_xyz'], fr['cnl_bbox_max_xyz'], 1024, 1024)
+    assert rays['rays'].shape[1] == 1024 * 1024                       # this camera sees the box in every pixel
+    keys = ['dst_Rs', 'dst_Ts', 'cnl_gtfms', 'motion_weights_priors', 'dst_posevec', 'cnl_bbox_min_xyz',
+            'cnl_bbox_scale_xyz', 'bgcolor']
+    data = {k: torch.from_numpy(np.ascontiguousarray(fr[k])).to(d) for k in keys}
+    data.update(rays=rays['rays'], near=rays['near'], far=rays['far'])
+    cfg.perturb, cfg.N_samples, cfg.amd.diagnostics = 0., 256, False
+    try:
+        with torch.no_grad():
+            out = net(**data, iter_val=1e7)
+            sel = torch.arange(0, 1024 * 1024, 4099, device=d)
+            sub = dict(data, rays=data['rays'][:, sel].contiguous(), near=data['near'][sel].contiguous(),
+                       far=data['far'][sel].contiguous())
+            alone = net(**sub, iter_val=1e7)
+    finally:
+        cfg.perturb, cfg.N_samples, cfg.amd.diagnostics = 1.0, 128, True
+    for k in ('rgb', 'alpha', 'depth'):
+        assert torch.isfinite(out[k]).all()
+        assert torch.equal(out[k][sel], alone[k]), k
+    assert 0.05 < float(out['alpha'].mean()) < 0.999
