@@ -196,6 +196,23 @@ def main():
                             'note': 'samples with fg likelihood < eps skip both MLPs; not the reference arithmetic, '
                                     'error bound 2*S*eps'}
 
+    if extras:
+        # the frame loop around the path (run.py:68-157): camera -> rays on the device (hnrf_gen_rays), render,
+        # scatter into the H x W image with background fill, 8-bit quantisation, asynchronous copy to the host
+        from humannerf_amd import render
+        cams = [scene.synthetic_frame(H=512, W=512, focal_at_512=1250.0, pose_seed=i % 2, camera_only=True)
+                for i in range(4)]
+        render.render_frames(net, cams[:1], device=dev)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        imgs = render.render_frames(net, cams, device=dev)
+        dt_p = time.perf_counter() - t0
+        result['frame_loop'] = {'frames_per_s_per_gpu': round(len(cams) / dt_p, 2), 'frames': len(cams),
+                                'image': '512x512, T-pose orbit camera (88 % of the pixels cross the bbox)',
+                                'includes': 'device ray generation + bbox test + compaction, render, image scatter, '
+                                            '8-bit quantisation, async D2H; excludes the SMPL pose helpers (numpy)',
+                                'mean_pixel': round(float(np.mean([imgs[i].mean() for i in imgs])), 3)}
+
     if extras and args.train_steps > 0:
         # second metric of BASELINE.json: train iters/s.  One iteration = 6 patches x 32x32 rays x 128
         # samples of this rank's frame (default.yaml:352-357), perturb = 1, loss 0.2*MSE vs a seeded
