@@ -139,6 +139,12 @@ def main():
                 'traffic': traffic, 'launches': launches, 'avg_launch_ms': round(avg_s * 1e3, 4),
                 'flop_per_launch': flop_per_launch,
                 'kernel_share_of_step': round(float(np.sum(k_ms)) * 1e-3 / elapsed, 4)}
+    if args.mode == 'f16x3':
+        # `peak` is the guide's nominal dense f16 peak / 3 (three MFMAs per product).  Measured on this part
+        # (profiles/r01_mfma_power.txt): a pure f16 MFMA stream with random operands is power-capped at
+        # 1.59 PFLOP/s (1.75 GHz, ~1225 W), i.e. 530 TFLOP/s for this scheme -- reported beside the contract's frac
+        roofline['power_capped_peak'] = 530.3
+        roofline['frac_of_power_capped_peak'] = round(achieved / 530.3, 4)
 
     result = {
         'metric': 'rendered rays/sec (128 samples/ray) at 512x512',
