@@ -183,6 +183,39 @@ def rays_intersect_3d_bbox(bounds, ray_o, ray_d):
     return np.minimum(d0, d1), np.maximum(d0, d1), hit
 
 
+def sample_patch_rays(ray_mask, subject_mask, bbox_mask, n_patch, patch_size, H, W, subject_ratio=0.8):
+    """Training-time ray selection (core/data/human_nerf/train.py:236-335): ``n_patch`` square windows whose
+    centres are drawn on the subject (probability ``subject_ratio``) or on the rest of the projected bbox; of each
+    window the pixels whose ray crosses the bbox are kept.  Draws from the GLOBAL numpy generator in the
+    reference's order (one ``rand`` and one ``choice`` per patch), so a seeded run picks the same patches.
+
+    ray_mask (H*W,) bool; subject_mask, bbox_mask (H, W) bool.  Returns
+    select_inds (indices into the compacted ray arrays), patch_info {'mask' (n,ps,ps), 'xy_min', 'xy_max' (n,2)},
+    patch_div_indices (n+1,)."""
+    assert ray_mask.dtype == bool and subject_mask.dtype == bool and bbox_mask.dtype == bool and ray_mask.ndim == 1
+    outside_subject = bbox_mask & ~subject_mask
+    compact_index = np.cumsum(ray_mask) - 1                    # pixel -> position among the kept rays
+    inds, masks, xy_min, xy_max, div = [], [], [], [], [0]
+    for _ in range(n_patch):
+        cand = subject_mask if np.random.rand(1)[0] < subject_ratio else outside_subject
+        ys, xs = np.where(cand)
+        pick = np.random.choice(ys.shape[0], size=[1], replace=False)[0]
+        half = patch_size // 2
+        x0 = np.clip(xs[pick] - half, 0, W - patch_size)
+        y0 = np.clip(ys[pick] - half, 0, H - patch_size)
+        window = np.zeros((H, W), dtype=bool)
+        window[y0:y0 + patch_size, x0:x0 + patch_size] = True
+        hit = window.reshape(-1) & ray_mask
+        inds.append(compact_index[np.where(hit)])
+        masks.append(hit.reshape(H, W)[y0:y0 + patch_size, x0:x0 + patch_size])
+        xy_min.append(np.array([x0, y0]))
+        xy_max.append(np.array([x0 + patch_size, y0 + patch_size]))
+        div.append(div[-1] + len(inds[-1]))
+    return (np.concatenate(inds, axis=0),
+            {'mask': np.stack(masks, axis=0), 'xy_min': np.stack(xy_min, axis=0), 'xy_max': np.stack(xy_max, axis=0)},
+            np.array(div))
+
+
 def tpose_camera(img_size, radius=6.0, focal=1250.0):
     """Orbit camera of the reference's T-pose renderer
     (core/data/human_nerf/tpose.py:65-84)."""

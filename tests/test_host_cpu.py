@@ -152,3 +152,26 @@ def test_conv_transpose_as_batched_gemm_matches_torch():
         g = torch.randn_like(ref)
         for a, r in zip(torch.autograd.grad(got, (x, w, b), g), torch.autograd.grad(ref, (x, w, b), g)):
             assert (a - r).abs().max() < 1e-11
+
+
+def test_patch_sampler_matches_reference(golden_dir):
+    """scene.sample_patch_rays against what the reference's Dataset.get_patch_ray_indices returned for the same
+    masks and the same seed of the global numpy generator (tests/golden/patches_s96.npz, oracle/make_golden_patches.py):
+    identical ray indices, patch masks (with holes at the rim of the bbox), window corners and split points."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, 'oracle'))
+    from humannerf_amd import scene
+    g = np.load(os.path.join(golden_dir, 'patches_s96.npz'))
+    H = W = 96
+    fr = scene.synthetic_frame(H=H, W=W, focal_at_512=1250.0)
+    yy, xx = np.mgrid[0:H, 0:W]
+    rim = (yy - H * 0.5) ** 2 / (H * 0.46) ** 2 + (xx - W * 0.5) ** 2 / (W * 0.30) ** 2 < 1.0
+    ray_mask = fr['ray_mask'].astype(bool) & rim.reshape(-1)
+    subject = ((yy - H * 0.5) ** 2 / (H * 0.36) ** 2 + (xx - W * 0.5) ** 2 / (W * 0.16) ** 2 < 1.0) & ray_mask.reshape(H, W)
+    np.random.seed(20240)
+    sel, info, div = scene.sample_patch_rays(ray_mask, subject, ray_mask.reshape(H, W).copy(), 6, 20, H, W,
+                                             subject_ratio=float(g['subject_ratio']))
+    assert np.array_equal(sel, g['select_inds']) and np.array_equal(div, g['div'])
+    assert np.array_equal(info['mask'], g['mask'])
+    assert np.array_equal(info['xy_min'], g['xy_min']) and np.array_equal(info['xy_max'], g['xy_max'])
+    assert (~g['mask']).any() and div[-1] < 6 * 400          # the fixture really has partly covered windows
