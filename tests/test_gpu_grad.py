@@ -265,3 +265,61 @@ def test_nonrigid_backward_chain_and_weight_gradients_match_autograd(mode):
     for l in range(7):
         assert rel(gW[l], w64[l].grad) <= 2e-5, l
         assert rel(gb[l], b64[l].grad) <= 2e-5, l
+
+
+@pytest.mark.parametrize('variant', ['tpose', 'early_iter', 'stratified'])
+def test_network_gradients_match_oracle_autograd_in_other_branches(seeded_params, variant):
+    """Branches of Network.forward the reference-gradient fixture does not visit, against torch.autograd through the
+    CPU oracle (itself pinned to the reference's gradients by tests/test_grad_oracle.py):
+    tpose = cfg.ignore_non_rigid_motions (network.py:264-277: no non-rigid MLP, its parameters get no gradient);
+    early_iter = iter_val below the pose-decoder / non-rigid kick-in (condition code zeroed, Hann window closed);
+    stratified = perturb > 0 with injected uniforms."""
+    from humannerf_amd import scene
+    from humannerf_amd.config import cfg
+    from humannerf_amd.network import Network
+    from oracle import oracle
+    fr = scene.synthetic_frame(H=512, W=512, focal_at_512=1250.0, ray_stride=97)
+    R = fr['rays'].shape[1]
+    rs = np.random.RandomState(3)
+    lw = rs.standard_normal((R, 5)).astype(np.float32)
+    t_rand = rs.uniform(size=(R, 64)).astype(np.float32) if variant == 'stratified' else None
+    iter_val = 100.0 if variant == 'early_iter' else 1e7
+    kw = dict(iter_val=iter_val, N_samples=64)
+    if variant == 'tpose':
+        kw['ignore_non_rigid_motions'] = True
+    if t_rand is not None:
+        kw['t_rand'] = torch.from_numpy(t_rand)
+    state = {k: torch.from_numpy(v).clone().requires_grad_(True) for k, v in seeded_params.items()}
+    ref_out = oracle.render(state, fr, **kw)
+    ref_loss = reference_loss(ref_out, lw)
+    ref_loss.backward()
+
+    net = Network()
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in seeded_params.items()})
+    net = net.to(dev()).train()
+    keys = ['rays', 'near', 'far', 'dst_Rs', 'dst_Ts', 'cnl_gtfms', 'motion_weights_priors', 'dst_posevec',
+            'cnl_bbox_min_xyz', 'cnl_bbox_scale_xyz', 'bgcolor']
+    data = {k: torch.from_numpy(np.ascontiguousarray(fr[k])).to(dev()) for k in keys}
+    if t_rand is not None:
+        data['t_rand'] = torch.from_numpy(t_rand).to(dev())
+    cfg.N_samples, cfg.perturb = 64, (1.0 if t_rand is not None else 0.0)
+    cfg.ignore_non_rigid_motions = variant == 'tpose'
+    try:
+        out = net(**data, iter_val=iter_val)
+        loss = reference_loss(out, torch.from_numpy(lw).to(dev()))
+        loss.backward()
+    finally:
+        cfg.N_samples, cfg.perturb, cfg.ignore_non_rigid_motions = 128, 1.0, False
+    assert abs(float(loss.detach()) - float(ref_loss.detach())) <= 2e-4 * max(1.0, abs(float(ref_loss.detach())))
+    checked = 0
+    for name, p in net.named_parameters():
+        ref = state[name].grad
+        got = p.grad
+        if ref is None or float(ref.norm()) == 0.0:
+            assert got is None or float(got.norm()) <= 1e-12, name
+            continue
+        g, r = got.double().cpu().reshape(-1), ref.double().reshape(-1)
+        assert abs(float(g.norm()) - float(r.norm())) <= 5e-3 * float(r.norm()), name
+        assert float(g @ r / (g.norm() * r.norm())) >= 0.999, name
+        checked += 1
+    assert checked >= (40 if variant != 'tpose' else 26)
