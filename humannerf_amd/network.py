@@ -300,7 +300,7 @@ class Network(nn.Module):
         self._vol_cache = None    # (key, priors, volume)
         self._workspace = None
         # set to a list to collect (start, stop) torch.cuda.Event pairs recorded around
-        # every canonical-MLP launch of the lean path (bench.py roofline)
+        # every canonical-MLP launch (bench.py roofline)
         self.mlp_event_log = None
 
     # reference API ---------------------------------------------------------
@@ -454,7 +454,14 @@ class Network(nn.Module):
             xyz, offsets = ops.nonrigid(x_skel, hann_w, nr_packed, mode, want_offsets=True)
         else:
             xyz, offsets = x_skel, torch.zeros_like(x_skel)                 # network.py:276-277
-        raw = ops.canonical(xyz, cnl_packed, mode)
+        if self.mlp_event_log is not None:
+            events = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            self.mlp_event_log.append(events)
+            events[0].record()
+            raw = ops.canonical(xyz, cnl_packed, mode)
+            events[1].record()
+        else:
+            raw = ops.canonical(xyz, cnl_packed, mode)
         out = ops.composite(raw, mask, z, rays_d, xyz, bg, diagnostics=True)
         out.update(xyz_on_rays=xyz, backward_motion_weights=bmw, offsets=offsets)
         return out
