@@ -404,6 +404,15 @@ class Network(nn.Module):
         diag = bool(amd_option('diagnostics', True))
 
         chunks = []
+        full = None
+        if not train_path and diag and N > int(cfg.chunk):
+            # whole-frame buffers for the 11 outputs: every chunk's kernels write their row range directly
+            # (the reference concatenates the per-chunk results, network.py:343-350: one more pass over 17 KB per ray)
+            B = motion_Rs.shape[0]
+            shp = {'rgb': (3,), 'alpha': (), 'depth': (), 'weights_on_rays': (S,), 'rgb_on_rays': (S, 3), 'cnl_xyz': (3,),
+                   'cnl_rgb': (3,), 'cnl_weight': (), 'xyz_on_rays': (S, 3), 'backward_motion_weights': (S, B),
+                   'offsets': (S, 3)}
+            full = {k: torch.empty((N,) + v, device=dev) for k, v in shp.items()}
         for i in range(0, N, int(cfg.chunk)):                              # network.py:333
             sl = slice(i, min(i + int(cfg.chunk), N))
             if train_path:
@@ -414,8 +423,12 @@ class Network(nn.Module):
             chunks.append(self._render_rays(rays_o[sl], rays_d[sl], near[sl], far[sl],
                                             None if t_rand is None else t_rand[sl],
                                             motion_Rs, motion_Ts, vol, bbox_min, bbox_scale, hann_w,
-                                            nr_packed, cnl_packed, bg, S, mode, diag))
-        out = {k: (torch.cat([c[k] for c in chunks], 0) if len(chunks) > 1 else chunks[0][k]) for k in chunks[0]}
+                                            nr_packed, cnl_packed, bg, S, mode, diag,
+                                            None if full is None else {k: v[sl] for k, v in full.items()}))
+        if full is not None:
+            out = full
+        else:
+            out = {k: (torch.cat([c[k] for c in chunks], 0) if len(chunks) > 1 else chunks[0][k]) for k in chunks[0]}
         lead = list(rays_shape[:-1])
         return {k: v.reshape(lead + list(v.shape[1:])) for k, v in out.items()}
 
@@ -434,8 +447,9 @@ class Network(nn.Module):
         return {'rgb': rgb, 'alpha': alpha, 'depth': depth}
 
     def _render_rays(self, rays_o, rays_d, near, far, t_rand, motion_Rs, motion_Ts, vol, bbox_min, bbox_scale,
-                     hann_w, nr_packed, cnl_packed, bg, S, mode, diag):
-        """network.py:474-602 for one ray chunk."""
+                     hann_w, nr_packed, cnl_packed, bg, S, mode, diag, dst=None):
+        """network.py:474-602 for one ray chunk.  ``dst``: this chunk's row range of the whole-frame output buffers
+        (full-signature path), written in place."""
         if not diag:
             need = ops.render_workspace_bytes(rays_o.shape[0], S) // 4 + 64
             if self._workspace is None or self._workspace.numel() < need or self._workspace.device != rays_o.device:
@@ -448,12 +462,18 @@ class Network(nn.Module):
                                    bbox_scale, hann_w, nr_packed, cnl_packed, bg, S, mode,
                                    workspace=self._workspace, mlp_events=events,
                                    cull_eps=float(amd_option('cull_eps', 0.0)))
+        g = (lambda k: None) if dst is None else dst.get
         z, x_skel, mask, bmw = ops.sample_warp(rays_o, rays_d, near, far, t_rand, motion_Rs, motion_Ts, vol,
-                                               bbox_min, bbox_scale, S, want_bmw=True)
+                                               bbox_min, bbox_scale, S, want_bmw=True,
+                                               bmw_out=g('backward_motion_weights'))
         if nr_packed is not None:
-            xyz, offsets = ops.nonrigid(x_skel, hann_w, nr_packed, mode, want_offsets=True)
+            xyz, offsets = ops.nonrigid(x_skel, hann_w, nr_packed, mode, want_offsets=True,
+                                        xyz_out=g('xyz_on_rays'), offsets_out=g('offsets'))
         else:
             xyz, offsets = x_skel, torch.zeros_like(x_skel)                 # network.py:276-277
+            if dst is not None:
+                dst['xyz_on_rays'].copy_(xyz)
+                dst['offsets'].zero_()
         if self.mlp_event_log is not None:
             events = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
             self.mlp_event_log.append(events)
@@ -462,6 +482,6 @@ class Network(nn.Module):
             events[1].record()
         else:
             raw = ops.canonical(xyz, cnl_packed, mode)
-        out = ops.composite(raw, mask, z, rays_d, xyz, bg, diagnostics=True)
+        out = ops.composite(raw, mask, z, rays_d, xyz, bg, diagnostics=True, out=dst)
         out.update(xyz_on_rays=xyz, backward_motion_weights=bmw, offsets=offsets)
         return out

@@ -36,9 +36,9 @@ def _ptr_array(tensors):
 
 
 def sample_warp(rays_o, rays_d, near, far, t_rand, motion_Rs, motion_Ts, vol, bbox_min, bbox_scale,
-                n_samples, want_bmw=False):
+                n_samples, want_bmw=False, bmw_out=None):
     """K1 (network.py:455-471, 499, 392-444).  Returns z_vals (R,S), x_skel (R,S,3),
-    fg_mask (R,S), bmw (R,S,B) or None."""
+    fg_mask (R,S), bmw (R,S,B) or None.  ``bmw_out``: contiguous (R,S,B) tensor to write bmw into."""
     lib = _lib.load()
     near, far = near.reshape(-1), far.reshape(-1)
     _chk(rays_o, rays_d, near, far, t_rand, motion_Rs, motion_Ts, vol, bbox_min, bbox_scale)
@@ -53,7 +53,10 @@ def sample_warp(rays_o, rays_d, near, far, t_rand, motion_Rs, motion_Ts, vol, bb
     z = torch.empty(R, S, device=dev)
     x_skel = torch.empty(R, S, 3, device=dev)
     mask = torch.empty(R, S, device=dev)
-    bmw = torch.empty(R, S, B, device=dev) if want_bmw else None
+    bmw = (bmw_out if bmw_out is not None else torch.empty(R, S, B, device=dev)) if want_bmw else None
+    if bmw is not None:
+        assert bmw.shape == (R, S, B)
+        _chk(bmw)
     _lib.check(lib.hnrf_sample_warp_fwd(_ptr(rays_o), _ptr(rays_d), _ptr(near), _ptr(far), _ptr(t_rand),
                                         _ptr(motion_Rs), _ptr(motion_Ts), _ptr(vol), _ptr(bbox_min),
                                         _ptr(bbox_scale), R, S, B, G, _ptr(z), _ptr(x_skel), _ptr(mask),
@@ -81,13 +84,15 @@ def nonrigid_pack(weights, biases, cond, mode='f32', out=None):
     return out
 
 
-def nonrigid(x_skel, hann_w, packed, mode='f32', want_offsets=False):
-    """K2 (hannw_fourier.py:21-49 + mlp_offset.py:74-114).  x_skel (...,3)."""
+def nonrigid(x_skel, hann_w, packed, mode='f32', want_offsets=False, xyz_out=None, offsets_out=None):
+    """K2 (hannw_fourier.py:21-49 + mlp_offset.py:74-114).  x_skel (...,3).  ``xyz_out`` / ``offsets_out``:
+    contiguous tensors of x_skel's shape to write into."""
     lib = _lib.load()
-    _chk(x_skel, hann_w, packed)
+    _chk(x_skel, hann_w, packed, xyz_out, offsets_out)
     P = x_skel.numel() // 3
-    xyz = torch.empty_like(x_skel)
-    offsets = torch.empty_like(x_skel) if want_offsets else None
+    xyz = xyz_out if xyz_out is not None else torch.empty_like(x_skel)
+    offsets = (offsets_out if offsets_out is not None else torch.empty_like(x_skel)) if want_offsets else None
+    assert xyz.shape == x_skel.shape and (offsets is None or offsets.shape == x_skel.shape)
     _lib.check(lib.hnrf_nonrigid_fwd(_ptr(x_skel), _ptr(hann_w), _ptr(packed), MLP_MODES[mode], P, _ptr(xyz),
                                      _ptr(offsets), _stream()), 'hnrf_nonrigid_fwd')
     return xyz, offsets
@@ -123,19 +128,24 @@ def canonical(xyz, packed, mode='f32'):
     return raw
 
 
-def composite(raw, fg_mask, z_vals, rays_d, xyz, bgcolor, diagnostics=True, cull_eps=0.0):
+def composite(raw, fg_mask, z_vals, rays_d, xyz, bgcolor, diagnostics=True, cull_eps=0.0, out=None):
     """K4 (network.py:355-388).  Returns dict with rgb/alpha/depth and, when
-    ``diagnostics``, weights_on_rays, rgb_on_rays, cnl_xyz, cnl_rgb, cnl_weight."""
+    ``diagnostics``, weights_on_rays, rgb_on_rays, cnl_xyz, cnl_rgb, cnl_weight.  ``out``: dict of contiguous
+    tensors of those shapes to write into (e.g. row ranges of whole-frame buffers)."""
     lib = _lib.load()
     _chk(raw, fg_mask, z_vals, rays_d, xyz, bgcolor)
     R, S = z_vals.shape
     dev = raw.device
-    out = {'rgb': torch.empty(R, 3, device=dev), 'alpha': torch.empty(R, device=dev),
-           'depth': torch.empty(R, device=dev)}
+    shapes = {'rgb': (R, 3), 'alpha': (R,), 'depth': (R,)}
     if diagnostics:
-        out.update(weights_on_rays=torch.empty(R, S, device=dev), rgb_on_rays=torch.empty(R, S, 3, device=dev),
-                   cnl_xyz=torch.empty(R, 3, device=dev), cnl_rgb=torch.empty(R, 3, device=dev),
-                   cnl_weight=torch.empty(R, device=dev))
+        shapes.update(weights_on_rays=(R, S), rgb_on_rays=(R, S, 3), cnl_xyz=(R, 3), cnl_rgb=(R, 3), cnl_weight=(R,))
+    if out is None:
+        out = {k: torch.empty(*sh, device=dev) for k, sh in shapes.items()}
+    else:
+        out = {k: out[k] for k in shapes}
+        for k, sh in shapes.items():
+            assert tuple(out[k].shape) == sh, (k, tuple(out[k].shape), sh)
+        _chk(*out.values())
     g = out.get
     _lib.check(lib.hnrf_composite_fwd(_ptr(raw), _ptr(fg_mask), _ptr(z_vals), _ptr(rays_d), _ptr(xyz),
                                       _ptr(bgcolor), R, S, float(cull_eps), _ptr(out['rgb']), _ptr(out['alpha']),
