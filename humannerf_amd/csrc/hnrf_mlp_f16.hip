@@ -510,14 +510,157 @@ __device__ __forceinline__ void layer16(Pipe& p, int nb1, int nb2, const h16x8 (
     }
 }
 
+// Two sample groups per wave (64 samples): every weight fragment read from LDS feeds six MFMAs instead of three
+// and the per-tile fixed costs (barrier, operand-queue priming, DMA issue) are paid once for twice the work.
+// Only the 128-wide non-rigid MLP has the registers for it (2 x 128 fragment registers per group); inference form
+// only.  bh / bl / oh / ol and `last` carry a leading group index; the PE stash holds group g at
+// wave * stash_per_wave + g * stash_per_wave / 2.
+template <int NT, int TPS, int NKA, int NKB, bool RELU, int NB, int NO>
+__device__ __forceinline__ void layer16x2(Pipe& p, unsigned stash_per_wave, int nb1, int nb2,
+                                          const h16x8 (&bh)[2][NB], const h16x8 (&bl)[2][NB], h16x8 (&oh)[2][NO],
+                                          h16x8 (&ol)[2][NO], float (&last)[2][16]) {
+    static_assert(NB >= (NKB > 0 ? NKB : 1) && NO >= 2 * NT && NT % TPS == 0, "bad layer shape");
+    constexpr int NK = NKA + NKB;
+    constexpr int NBLK = 2 * NK;
+    constexpr int NS = NT / TPS;
+    constexpr int PFK = NK < 4 ? NK : 4;
+    static_assert((NBLK * TPS) % 4 == 0, "every wave must issue the same number of DMA pieces per slab");
+    const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    f32x16 pacc1[2] = {zero, zero}, pacc2[2] = {zero, zero};
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        const int nissue = (s + 2 < NS) ? NBLK * TPS : (s + 2 == NS ? nb1 : nb2);
+        const unsigned slot2 = p.ph == 0 ? 2 : p.ph - 1;
+        const char* dsrc = p.gi + p.wave * 1024;
+        const unsigned ddst = p.lds_base + p.ring_off + slot2 * p.slab_bytes + p.wave * 1024;
+        const int dcnt = nissue / 4;
+        p.gi += nissue * 1024;
+#pragma unroll
+        for (int tt = 0; tt < TPS; ++tt) {
+            const int t = s * TPS + tt;
+            const unsigned lane = lane_now();
+            const unsigned cur = p.lds_base + p.ring_off + p.ph * p.slab_bytes + tt * (NBLK * 1024) + lane * 16;
+            const unsigned pe = p.lds_base + p.pe_off + p.wave * stash_per_wave + lane * 16;
+            f32x16 acc1[2] = {zero, zero}, acc2[2] = {zero, zero};
+            if (NT > 1) {
+                const unsigned bp = p.lds_base + p.bias_off + tt * 128 + (lane >> 5) * 16;
+                const f32x4 b0 = lds_ld4f(bp), b1 = lds_ld4f(bp + 32), b2 = lds_ld4f(bp + 64), b3 = lds_ld4f(bp + 96);
+                acc1[0] = f32x16{b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w,
+                                 b2.x, b2.y, b2.z, b2.w, b3.x, b3.y, b3.z, b3.w};
+                acc1[1] = acc1[0];
+            }
+            h16x8 qwh[PFK], qwl[PFK], qxh[2][PFK], qxl[2][PFK];
+#pragma unroll
+            for (int i = 0; i < PFK; ++i) {
+                qwh[i] = lds_ld8(cur + (2 * i) * 1024);
+                qwl[i] = lds_ld8(cur + (2 * i + 1) * 1024);
+                if (i < NKA) {
+#pragma unroll
+                    for (int g = 0; g < 2; ++g) {
+                        qxh[g][i] = lds_ld8(pe + g * (stash_per_wave / 2) + (2 * i) * 1024);
+                        qxl[g][i] = lds_ld8(pe + g * (stash_per_wave / 2) + (2 * i + 1) * 1024);
+                    }
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int ks = 0; ks < NK; ++ks) {
+                const int q = ks % PFK;
+                const h16x8 wh = qwh[q], wl = qwl[q];
+                h16x8 xh[2], xl[2];
+#pragma unroll
+                for (int g = 0; g < 2; ++g) {
+                    if (ks < NKA) {
+                        xh[g] = qxh[g][q];
+                        xl[g] = qxl[g][q];
+                    } else {
+                        const int ib = ks - NKA < NB ? ks - NKA : 0;
+                        xh[g] = bh[g][ib];
+                        xl[g] = bl[g][ib];
+                    }
+                }
+                if (ks + PFK < NK) {
+                    qwh[q] = lds_ld8(cur + (2 * (ks + PFK)) * 1024);
+                    qwl[q] = lds_ld8(cur + (2 * (ks + PFK) + 1) * 1024);
+                    if (ks + PFK < NKA) {
+#pragma unroll
+                        for (int g = 0; g < 2; ++g) {
+                            qxh[g][q] = lds_ld8(pe + g * (stash_per_wave / 2) + (2 * (ks + PFK)) * 1024);
+                            qxl[g][q] = lds_ld8(pe + g * (stash_per_wave / 2) + (2 * (ks + PFK) + 1) * 1024);
+                        }
+                    }
+                }
+#pragma unroll
+                for (int g = 0; g < 2; ++g) {
+                    acc1[g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, xh[g], acc1[g], 0, 0, 0);
+                    acc2[g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, xl[g], acc2[g], 0, 0, 0);
+                    acc2[g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, xh[g], acc2[g], 0, 0, 0);
+                }
+                {
+                    constexpr int MAXP = (TPS * NK - 1) < 10 ? (TPS * NK - 1) : 10;
+                    const int i = tt * NK + ks - 1;
+                    if (i >= 0 && i < MAXP) {
+                        if (s + 2 < NS) {
+                            if (i < NBLK * TPS / 4) dma_piece(dsrc + i * 4096, lane * 16, ddst + i * 4096);
+                        } else if (i < dcnt) {
+                            dma_piece(dsrc + i * 4096, lane * 16, ddst + i * 4096);
+                        }
+                    }
+                }
+                if (t > 0) {      // pending epilogue of tile t-1: 16 pair-units (2 groups x 8), unit j at k-step (j NK) / 16
+#pragma unroll
+                    for (int j = 0; j < 16; ++j)
+                        if ((j * NK) / 16 == ks) {
+                            const int g = j >> 3, i = j & 7;
+                            epi_pair<RELU>(pacc1[g], pacc2[g], i, oh[g][2 * (t - 1) + (i >> 2)], ol[g][2 * (t - 1) + (i >> 2)]);
+                            asm volatile("" : "+v"(oh[g][2 * (t - 1) + (i >> 2)]), "+v"(ol[g][2 * (t - 1) + (i >> 2)]));
+                        }
+                }
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int g = 0; g < 2; ++g) { pacc1[g] = acc1[g]; pacc2[g] = acc2[g]; }
+        }
+        tile_sync(nissue / 4);
+        p.ph = p.ph == RING - 1 ? 0 : p.ph + 1;
+        p.bias_off += TPS * 128;
+    }
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+        if (NT == 1) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) last[g][r] = pacc1[g][r] + pacc2[g][r] * LO_INV;
+        } else {
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                epi_pair<RELU>(pacc1[g], pacc2[g], i, oh[g][2 * (NT - 1) + (i >> 2)], ol[g][2 * (NT - 1) + (i >> 2)]);
+        }
+    }
+}
+
 // Starts the pipeline: bias table + the first two slabs are put in flight.
 __device__ __forceinline__ Pipe pipe_start(const char* packed, int64_t bias_img_off, int bias_bytes, int slab_bytes,
-                                           int nb0, int nb1, char* smem) {
+                                           int nb0, int nb1, char* smem, int stash_bytes = PE_STASH) {
     Pipe p;
     p.wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     p.lds_base = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lds_char*)smem);
     p.pe_off = bias_bytes;
-    p.ring_off = bias_bytes + PE_STASH;
+    p.ring_off = bias_bytes + stash_bytes;
     p.slab_bytes = slab_bytes;
     p.ph = 0;
     p.bias_off = 0;
@@ -713,6 +856,100 @@ __global__ __launch_bounds__(256) void nonrigid_f16x3_kernel(const float* __rest
             offsets[sample * 3 + 0] = o0;
             offsets[sample * 3 + 1] = o1;
             offsets[sample * 3 + 2] = o2;
+        }
+    }
+}
+
+// K2, f16x3, two sample groups per wave (inference): grid = ceil(P / 256) workgroups of 4 waves x 64 samples.
+// LDS = 3 KiB bias + 64 KiB PE stash (4 waves x 2 groups x 8 KiB) + 3 x 24 KiB slabs = 139 KiB; the weight image is
+// the one nonrigid16_pack writes (tiles are consecutive; only the grouping into slabs differs: L0 2 tiles per slab,
+// one tile per slab elsewhere).
+constexpr int NR16X2_SLAB = 24 * 1024;
+constexpr int NR16X2_STASH = 64 * 1024;
+
+__global__ __launch_bounds__(256) void nonrigid_f16x3_x2_kernel(const float* __restrict__ x_skel,
+                                                                const float* __restrict__ hann_w,
+                                                                const char* __restrict__ packed, int64_t P,
+                                                                float* __restrict__ xyz, float* __restrict__ offsets,
+                                                                const int* __restrict__ idx,
+                                                                const int* __restrict__ count) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    if (idx != nullptr) {
+        P = *count;
+        if ((int64_t)blockIdx.x * 256 >= P) return;
+    }
+    // pipe_start lays the LDS out as [bias | PE_STASH | ring]: the stash of this kernel is twice as large
+    Pipe p = pipe_start(packed, NR16_BIAS, NR16_BIAS_LDS, NR16X2_SLAB, 2 * NR16_NB_L0, 2 * NR16_NB_L0, smem,
+                        NR16X2_STASH);
+    constexpr unsigned SPW = NR16X2_STASH / 4;                  // stash bytes per wave
+    const int lane = threadIdx.x & 63, h = lane >> 5;
+    int64_t sidx[2];
+    bool live[2];
+    float x[2][3];
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+        const int64_t slot = ((int64_t)blockIdx.x * 4 + p.wave) * 64 + g * 32 + (lane & 31);
+        const int64_t sclamp = slot < P ? slot : P - 1;
+        sidx[g] = idx ? (int64_t)idx[sclamp] : sclamp;
+        live[g] = slot < P;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) x[g][a] = x_skel[sidx[g] * 3 + a];
+    }
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+        float pev[32];
+        OctavePhase ph[3] = {OctavePhase(x[g][0]), OctavePhase(x[g][1]), OctavePhase(x[g][2])};
+#pragma unroll
+        for (int a = 0; a < 18; ++a) {
+            float sv, cv;
+            ph[a % 3].next(sv, cv);
+            pev[a] = hann_w[a / 3] * (h ? cv : sv);
+        }
+#pragma unroll
+        for (int a = 18; a < 32; ++a) pev[a] = 0.f;
+        const unsigned pe = p.lds_base + p.pe_off + p.wave * SPW + g * (SPW / 2) + lane_now() * 16;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const float v[8] = {pev[8 * ks], pev[8 * ks + 1], pev[8 * ks + 2], pev[8 * ks + 3],
+                                pev[8 * ks + 4], pev[8 * ks + 5], pev[8 * ks + 6], pev[8 * ks + 7]};
+            h16x8 hi, lo;
+            split8(v, hi, lo);
+            lds_st8(pe + (2 * ks) * 1024, hi);
+            lds_st8(pe + (2 * ks + 1) * 1024, lo);
+        }
+    }
+    tile_sync(0);
+
+    h16x8 hA_h[2][8], hA_l[2][8], hB_h[2][8], hB_l[2][8];
+    float last[2][16];
+    constexpr int MID = NR16_NB_MID, L4B = NR16_NB_L4;          // blocks per tile: 16 / 24
+    layer16x2<4, 2, 4, 0, true>(p, SPW, MID, MID, hB_h, hB_l, hA_h, hA_l, last);            // L0 (hB unused: NKB = 0)
+#pragma unroll 1
+    for (int l = 1; l <= 3; ++l) {
+        const int nb = l == 3 ? L4B : MID;
+        layer16x2<4, 1, 0, 8, true>(p, SPW, nb, nb, hA_h, hA_l, hB_h, hB_l, last);
+#pragma unroll
+        for (int g = 0; g < 2; ++g)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { hA_h[g][i] = hB_h[g][i]; hA_l[g][i] = hB_l[g][i]; }
+    }
+    layer16x2<4, 1, 4, 8, true>(p, SPW, MID, MID, hA_h, hA_l, hB_h, hB_l, last);             // skip layer
+    layer16x2<4, 1, 0, 8, true>(p, SPW, MID, 0, hB_h, hB_l, hA_h, hA_l, last);
+    h16x8 dh[2][2], dl[2][2];
+    layer16x2<1, 1, 0, 8, false>(p, SPW, 0, 0, hA_h, hA_l, dh, dl, last);
+    const float* ob = reinterpret_cast<const float*>(packed + NR16_BIAS + NR16_BIAS_LDS);
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+        if (h == 0 && live[g]) {
+            const float o0 = last[g][0] + ob[0], o1 = last[g][1] + ob[1], o2 = last[g][2] + ob[2];
+            xyz[sidx[g] * 3 + 0] = x[g][0] + o0;
+            xyz[sidx[g] * 3 + 1] = x[g][1] + o1;
+            xyz[sidx[g] * 3 + 2] = x[g][2] + o2;
+            if (offsets) {
+                offsets[sidx[g] * 3 + 0] = o0;
+                offsets[sidx[g] * 3 + 1] = o1;
+                offsets[sidx[g] * 3 + 2] = o2;
+            }
         }
     }
 }
@@ -1085,8 +1322,12 @@ int nonrigid16_fwd(const float* x_skel, const float* hann_w, const void* packed,
     constexpr int lds = NR16_BIAS_LDS + PE_STASH + RING * NR16_SLAB;
     static unsigned long long lds_done = 0;
     if (int rc = reserve_lds((const void*)nonrigid_f16x3_kernel<false>, lds, lds_done, "hnrf_nonrigid_fwd (f16x3)")) return rc;
-    hipLaunchKernelGGL(nonrigid_f16x3_kernel<false>, dim3((unsigned)((P + 127) / 128)), dim3(256), lds, st, x_skel, hann_w,
-                       (const char*)packed, P, xyz, offsets, idx, count, nullptr, nullptr, nullptr);
+    (void)lds;
+    constexpr int lds2 = NR16_BIAS_LDS + NR16X2_STASH + RING * NR16X2_SLAB;
+    static unsigned long long lds2_done = 0;
+    if (int rc = reserve_lds((const void*)nonrigid_f16x3_x2_kernel, lds2, lds2_done, "hnrf_nonrigid_fwd (f16x3)")) return rc;
+    hipLaunchKernelGGL(nonrigid_f16x3_x2_kernel, dim3((unsigned)((P + 255) / 256)), dim3(256), lds2, st, x_skel, hann_w,
+                       (const char*)packed, P, xyz, offsets, idx, count);
     return check_launch("hnrf_nonrigid_fwd (f16x3)");
 }
 
