@@ -323,3 +323,49 @@ def test_network_gradients_match_oracle_autograd_in_other_branches(seeded_params
         assert float(g @ r / (g.norm() * r.norm())) >= 0.999, name
         checked += 1
     assert checked >= (40 if variant != 'tpose' else 26)
+
+
+def test_training_gradients_are_additive_over_ray_subsets_at_full_size(seeded_params):
+    """Size-independent property at BASELINE's training size (6 144 rays x 128 samples = 786 k samples, where the
+    oracle is too slow): for a loss that is a sum over rays, the gradient of the whole batch equals the sum of the
+    gradients of its two halves -- through the split-f16 forward, both dX chains, the slice-reduced dW kernels, K1'
+    and the decoder.  Also: running the same batch twice gives bit-identical gradients (no atomics on the MLP path
+    whose order could matter ... the weight-volume / motion-base gradients use float atomics and are compared with
+    a tolerance)."""
+    from humannerf_amd import scene
+    from humannerf_amd.config import cfg
+    from humannerf_amd.network import Network
+    d = dev()
+    fr = scene.synthetic_frame(H=512, W=512, focal_at_512=1700.0)
+    idx = (np.arange(6144) * 37) % (512 * 512)
+    keys = ['rays', 'near', 'far', 'dst_Rs', 'dst_Ts', 'cnl_gtfms', 'motion_weights_priors', 'dst_posevec',
+            'cnl_bbox_min_xyz', 'cnl_bbox_scale_xyz', 'bgcolor']
+    data = {k: torch.from_numpy(np.ascontiguousarray(fr[k])).to(d) for k in keys}
+    lw = torch.from_numpy(np.random.RandomState(7).standard_normal((6144, 3)).astype(np.float32)).to(d)
+    net = Network()
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in seeded_params.items()})
+    net = net.to(d).train()
+
+    def grads(sel):
+        net.zero_grad(set_to_none=True)
+        sub = dict(data, rays=data['rays'][:, idx[sel]].contiguous(), near=data['near'][idx[sel]].contiguous(),
+                   far=data['far'][idx[sel]].contiguous())
+        out = net(**sub, iter_val=1e7)
+        (out['rgb'] * lw[sel]).sum().backward()
+        return {k: p.grad.detach().clone() for k, p in net.named_parameters() if p.grad is not None}
+
+    cfg.N_samples, cfg.perturb = 128, 0.0
+    try:
+        whole = grads(np.arange(6144))
+        again = grads(np.arange(6144))
+        a, b = grads(np.arange(0, 3072)), grads(np.arange(3072, 6144))
+    finally:
+        cfg.perturb = 1.0
+    assert len(whole) >= 50
+    for k, g in whole.items():
+        scale = float(g.abs().max()) + 1e-30
+        mlp = 'cnl_mlp' in k or 'non_rigid_mlp' in k
+        rep = float((g - again[k]).abs().max()) / scale
+        assert rep == 0.0 if mlp else rep <= 1e-4, (k, rep)
+        err = float((g - (a[k] + b[k])).abs().max()) / scale
+        assert err <= 2e-4, (k, err)
