@@ -165,7 +165,7 @@ constexpr int DW16_DEPTH = 4;      // k-steps of raw global loads in flight (als
 __device__ __forceinline__ void split_pair(float v0, float v1, _Float16& h0, _Float16& h1, _Float16& l0, _Float16& l1) {
     const f32x2v p = {__builtin_amdgcn_fmed3f(v0, -65504.f, 65504.f), __builtin_amdgcn_fmed3f(v1, -65504.f, 65504.f)};
     const h16x2 hh = __builtin_convertvector(p, h16x2);
-    const f32x2v r = p - __builtin_convertvector(hh, f32x2v);
+    const f32x2v r = {fmaf((float)hh[0], -1.0f, p[0]), fmaf((float)hh[1], -1.0f, p[1])};   // v_fma_mix_f32, exact
     const h16x2 ll = __builtin_convertvector(r, h16x2);
     h0 = hh[0]; h1 = hh[1]; l0 = ll[0]; l1 = ll[1];
 }

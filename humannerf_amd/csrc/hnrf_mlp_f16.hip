@@ -200,8 +200,7 @@ __device__ __forceinline__ void split8(const float (&v)[8], h16x8& hi, h16x8& lo
     for (int i = 0; i < 4; ++i) {
         const f32x2 p = {v[2 * i], v[2 * i + 1]};
         const h16x2 hh = __builtin_convertvector(p, h16x2);
-        const f32x2 back = __builtin_convertvector(hh, f32x2);
-        const f32x2 rem = (p - back) * LO_SCALE;
+        const f32x2 rem = {fmaf((float)hh[0], -LO_SCALE, p[0] * LO_SCALE), fmaf((float)hh[1], -LO_SCALE, p[1] * LO_SCALE)};
         const h16x2 ll = __builtin_convertvector(rem, h16x2);
         hi[2 * i] = hh[0];
         hi[2 * i + 1] = hh[1];
@@ -238,9 +237,9 @@ __device__ __forceinline__ void epi_pair(const f32x16& a1, const f32x16& a2, int
         x1 = __builtin_amdgcn_fmed3f(x1, 0.f, 65504.f);
     }
     const h16x2 hh = __builtin_convertvector(f32x2{x0, x1}, h16x2);
-    // (x - hi) * 2^11 == fma(x, 2^11, -(hi * 2^11)): both products exact
-    const float r0 = fmaf(x0, LO_SCALE, -((float)hh[0] * LO_SCALE));
-    const float r1 = fmaf(x1, LO_SCALE, -((float)hh[1] * LO_SCALE));
+    // (x - hi) * 2^11, exact; written so that hipcc folds the f16 -> f32 conversion into v_fma_mix_f32
+    const float r0 = fmaf((float)hh[0], -LO_SCALE, x0 * LO_SCALE);
+    const float r1 = fmaf((float)hh[1], -LO_SCALE, x1 * LO_SCALE);
     const h16x2 ll = __builtin_convertvector(f32x2{r0, r1}, h16x2);
     const int e = 2 * (i & 3);
     hi[e] = hh[0];
@@ -260,8 +259,9 @@ __device__ __forceinline__ void epi_pair_x(const f32x16& a1, const f32x16& a2, i
         x1 = __builtin_amdgcn_fmed3f(x1, 0.f, 65504.f);
     }
     const h16x2 hh = __builtin_convertvector(f32x2{x0, x1}, h16x2);
-    const float r0 = fmaf(x0, LO_SCALE, -((float)hh[0] * LO_SCALE));
-    const float r1 = fmaf(x1, LO_SCALE, -((float)hh[1] * LO_SCALE));
+    // (x - hi) * 2^11, exact; written so that hipcc folds the f16 -> f32 conversion into v_fma_mix_f32
+    const float r0 = fmaf((float)hh[0], -LO_SCALE, x0 * LO_SCALE);
+    const float r1 = fmaf((float)hh[1], -LO_SCALE, x1 * LO_SCALE);
     const h16x2 ll = __builtin_convertvector(f32x2{r0, r1}, h16x2);
     const int e = 2 * (i & 3);
     hi[e] = hh[0];
@@ -296,8 +296,9 @@ __device__ __forceinline__ void epi_pair_m(const f32x16& a1, const f32x16& a2, i
     x0 = (mbits >> (2 * i)) & 1u ? __builtin_amdgcn_fmed3f(x0, -65504.f, 65504.f) : 0.f;
     x1 = (mbits >> (2 * i + 1)) & 1u ? __builtin_amdgcn_fmed3f(x1, -65504.f, 65504.f) : 0.f;
     const h16x2 hh = __builtin_convertvector(f32x2{x0, x1}, h16x2);
-    const float r0 = fmaf(x0, LO_SCALE, -((float)hh[0] * LO_SCALE));
-    const float r1 = fmaf(x1, LO_SCALE, -((float)hh[1] * LO_SCALE));
+    // (x - hi) * 2^11, exact; written so that hipcc folds the f16 -> f32 conversion into v_fma_mix_f32
+    const float r0 = fmaf((float)hh[0], -LO_SCALE, x0 * LO_SCALE);
+    const float r1 = fmaf((float)hh[1], -LO_SCALE, x1 * LO_SCALE);
     const h16x2 ll = __builtin_convertvector(f32x2{r0, r1}, h16x2);
     const int e = 2 * (i & 3);
     hi[e] = hh[0];
