@@ -710,17 +710,9 @@ __global__ __launch_bounds__(256) void canonical_f16x3_kernel(const float* __res
     // positional encoding -> LDS stash, while the first slabs fly
     const float x[3] = {xyz[sidx * 3 + 0], xyz[sidx * 3 + 1], xyz[sidx * 3 + 2]};
     float pev[32];                                // argument a = 3 k + axis; a = 30, 31: raw x
-    {
-        OctavePhase ph[3] = {OctavePhase(x[0]), OctavePhase(x[1]), OctavePhase(x[2])};
-#pragma unroll
-        for (int a = 0; a < 30; ++a) {
-            float sv, cv;
-            ph[a % 3].next(sv, cv);
-            pev[a] = h ? cv : sv;
-        }
-        pev[30] = h ? x[1] : x[0];
-        pev[31] = h ? 0.f : x[2];
-    }
+    pe_sincos_shared<10>(x, h, pev);
+    pev[30] = h ? x[1] : x[0];
+    pev[31] = h ? 0.f : x[2];
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
         const float v[8] = {pev[8 * ks], pev[8 * ks + 1], pev[8 * ks + 2], pev[8 * ks + 3],
@@ -802,17 +794,11 @@ __global__ __launch_bounds__(256) void nonrigid_f16x3_kernel(const float* __rest
 
     const float x[3] = {x_skel[sidx * 3 + 0], x_skel[sidx * 3 + 1], x_skel[sidx * 3 + 2]};
     float pev[32];
-    {
-        OctavePhase ph[3] = {OctavePhase(x[0]), OctavePhase(x[1]), OctavePhase(x[2])};
+    pe_sincos_shared<6>(x, h, pev);
 #pragma unroll
-        for (int a = 0; a < 18; ++a) {
-            float sv, cv;
-            ph[a % 3].next(sv, cv);
-            pev[a] = hann_w[a / 3] * (h ? cv : sv);
-        }
+    for (int a = 0; a < 18; ++a) pev[a] *= hann_w[a / 3];
 #pragma unroll
-        for (int a = 18; a < 32; ++a) pev[a] = 0.f;
-    }
+    for (int a = 18; a < 32; ++a) pev[a] = 0.f;
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
         const float v[8] = {pev[8 * ks], pev[8 * ks + 1], pev[8 * ks + 2], pev[8 * ks + 3],
@@ -899,13 +885,9 @@ __global__ __launch_bounds__(256) void nonrigid_f16x3_x2_kernel(const float* __r
 #pragma unroll
     for (int g = 0; g < 2; ++g) {
         float pev[32];
-        OctavePhase ph[3] = {OctavePhase(x[g][0]), OctavePhase(x[g][1]), OctavePhase(x[g][2])};
+        pe_sincos_shared<6>(x[g], h, pev);
 #pragma unroll
-        for (int a = 0; a < 18; ++a) {
-            float sv, cv;
-            ph[a % 3].next(sv, cv);
-            pev[a] = hann_w[a / 3] * (h ? cv : sv);
-        }
+        for (int a = 0; a < 18; ++a) pev[a] *= hann_w[a / 3];
 #pragma unroll
         for (int a = 18; a < 32; ++a) pev[a] = 0.f;
         const unsigned pe = p.lds_base + p.pe_off + p.wave * SPW + g * (SPW / 2) + lane_now() * 16;

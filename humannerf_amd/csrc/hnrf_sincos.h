@@ -47,6 +47,48 @@ struct OctavePhase {
         u = f + f;
         sincos_rev((float)f, s, c);
     }
+    // the same octave sequence taken two at a time (4 f is as exact as 2 (2 f)): skip() moves one octave on
+    // without evaluating, next2() evaluates this octave and moves two on
+    __device__ __forceinline__ void skip() {
+        const double f = u - rint(u);
+        u = f + f;
+    }
+    __device__ __forceinline__ void next2(float& s, float& c) {
+        const double f = u - rint(u);
+        u = 4.0 * f;
+        sincos_rev((float)f, s, c);
+    }
 };
+
+// Value held by the partner lane (lane ^ 32) -- the other half of the same sample in the MLP kernels' layout.
+__device__ __forceinline__ float swap32(float v, int h) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float(h ? r[0] : r[1]);
+}
+
+// Positional-encoding values of one sample in the MLP kernels' B-operand order: out[3 k + axis] = sin (lane half 0)
+// or cos (lane half 1) of 2^k x[axis], k < NB (even).  The two lanes of a sample share the work: half h evaluates
+// the octaves of parity h (sin AND cos come out of one evaluation), keeps the one it needs and hands the other to
+// its partner with one v_permlane32_swap -- 3 NB / 2 evaluations per lane instead of 3 NB, bit-identical values.
+template <int NB>
+__device__ __forceinline__ void pe_sincos_shared(const float (&x)[3], int h, float* out) {
+    static_assert(NB % 2 == 0, "octaves are taken in pairs");
+    OctavePhase ph[3] = {OctavePhase(x[0]), OctavePhase(x[1]), OctavePhase(x[2])};
+    if (h) {
+#pragma unroll
+        for (int a = 0; a < 3; ++a) ph[a].skip();
+    }
+#pragma unroll
+    for (int k2 = 0; k2 < NB / 2; ++k2)
+#pragma unroll
+        for (int ax = 0; ax < 3; ++ax) {
+            float sv, cv;
+            ph[ax].next2(sv, cv);
+            const float own = h ? cv : sv;
+            const float recv = swap32(h ? sv : cv, h);
+            out[6 * k2 + ax] = h ? recv : own;          // octave 2 k2
+            out[6 * k2 + 3 + ax] = h ? own : recv;      // octave 2 k2 + 1
+        }
+}
 
 }  // namespace hnrf

@@ -369,3 +369,28 @@ def test_training_gradients_are_additive_over_ray_subsets_at_full_size(seeded_pa
         assert rep == 0.0 if mlp else rep <= 1e-4, (k, rep)
         err = float((g - (a[k] + b[k])).abs().max()) / scale
         assert err <= 2e-4, (k, err)
+
+
+def test_shared_pe_evaluation_is_bit_identical():
+    """The split-f16 kernels let the two lanes of a sample share the sin/cos evaluations (hnrf_sincos.h,
+    pe_sincos_shared); the fp32 kernels evaluate everything on every lane.  Same octave phases, same polynomials:
+    the saved positional encodings must agree bit for bit (canonical: 10 bands; non-rigid: 6 bands x Hann weights)."""
+    from humannerf_amd import ops
+    from tests.test_gpu_parity import _mlp_states
+    rs = np.random.RandomState(21)
+    st = _mlp_states(rs)
+    P = 4099
+    x = rs.uniform(-1.3, 1.3, (P, 3)).astype(np.float32)
+    x[0] = [0.0, 1e-30, -1.0]                      # zero, a denormal-scale argument, an exact turn fraction
+    T = lambda a: torch.from_numpy(a).to(dev())
+    idx = [0, 2, 4, 6, 8, 10, 12, 14]
+    cw = [T(st[f'cnl_mlp.module.pts_linears.{i}.weight']) for i in idx] + [T(st['cnl_mlp.module.output_linear.0.weight'])]
+    cb = [T(st[f'cnl_mlp.module.pts_linears.{i}.bias']) for i in idx] + [T(st['cnl_mlp.module.output_linear.0.bias'])]
+    pes = [ops.canonical_train(T(x), ops.canonical_pack(cw, cb, m), m)[1] for m in ('f32', 'f16x3')]
+    assert torch.equal(pes[0], pes[1])
+    names = [f'non_rigid_mlp.module.block_mlps.{i}' for i in (0, 2, 4, 6, 8, 10, 12)]
+    nw, nb = [T(st[n + '.weight']) for n in names], [T(st[n + '.bias']) for n in names]
+    hann = T(np.array([1.0, 1.0, 0.75, 0.25, 0.5, 0.0], np.float32))
+    cond = T(np.zeros(69, np.float32))
+    pen = [ops.nonrigid_train(T(x), hann, ops.nonrigid_pack(nw, nb, cond, m), m)[2] for m in ('f32', 'f16x3')]
+    assert torch.equal(pen[0], pen[1])
