@@ -106,8 +106,10 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
+    out = None
     for _ in range(args.steps):
-        out = step()
+        out = None          # a frame is consumed before the next one is rendered: do not hold two sets of the
+        out = step()        # 13.5 GB of per-sample outputs (a second set means fresh hipMallocs inside the timed loop)
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
