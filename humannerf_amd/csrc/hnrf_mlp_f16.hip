@@ -373,8 +373,12 @@ __device__ __forceinline__ void layer16(Pipe& p, int nb1, int nb2, const h16x8 (
         for (int tt = 0; tt < TPS; ++tt) {
             const int t = s * TPS + tt;
             const unsigned lane = lane_now();
-            const unsigned cur = p.lds_base + p.ring_off + p.ph * p.slab_bytes + tt * (NBLK * 1024) + lane * 16;
-            const unsigned pe = p.lds_base + p.pe_off + p.wave * (PE_STASH / 4) + lane * 16;
+            unsigned cur = p.lds_base + p.ring_off + p.ph * p.slab_bytes + tt * (NBLK * 1024) + lane * 16;
+            unsigned pe = p.lds_base + p.pe_off + p.wave * (PE_STASH / 4) + lane * 16;
+            // opaque to constant propagation: where the ring slot is known at compile time hipcc otherwise builds
+            // every operand address as (absolute constant + lane offset) with a v_add per ds_read instead of using
+            // the instruction's immediate offset on one base register
+            asm volatile("" : "+v"(cur), "+v"(pe));
             f32x16 acc1 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
             f32x16 acc2 = acc1;
             if (NT > 1 && SAVE < 2) {                      // (the backward stages have no bias)
@@ -540,8 +544,9 @@ __device__ __forceinline__ void layer16x2(Pipe& p, unsigned stash_per_wave, int 
         for (int tt = 0; tt < TPS; ++tt) {
             const int t = s * TPS + tt;
             const unsigned lane = lane_now();
-            const unsigned cur = p.lds_base + p.ring_off + p.ph * p.slab_bytes + tt * (NBLK * 1024) + lane * 16;
-            const unsigned pe = p.lds_base + p.pe_off + p.wave * stash_per_wave + lane * 16;
+            unsigned cur = p.lds_base + p.ring_off + p.ph * p.slab_bytes + tt * (NBLK * 1024) + lane * 16;
+            unsigned pe = p.lds_base + p.pe_off + p.wave * stash_per_wave + lane * 16;
+            asm volatile("" : "+v"(cur), "+v"(pe));        // see layer16
             f32x16 acc1[2] = {zero, zero}, acc2[2] = {zero, zero};
             if (NT > 1) {
                 const unsigned bp = p.lds_base + p.bias_off + tt * 128 + (lane >> 5) * 16;
