@@ -354,6 +354,8 @@ __device__ __forceinline__ void layer16(Pipe& p, int nb1, int nb2, const h16x8 (
     static_assert((NBLK * TPS) % 4 == 0, "every wave must issue the same number of DMA pieces per slab");
     f32x16 pacc1 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     f32x16 pacc2 = pacc1;                    // accumulators of the previous tile (epilogue pending)
+    f32x16 nbias = pacc1;                    // bias of the NEXT tile: the table is resident in LDS, so it is read
+                                             // during the current tile instead of on the critical path behind the barrier
     uint32_t bw[(NT + 1) / 2];               // SAVE: sign mask of this layer's outputs (this lane half)
 #pragma unroll
     for (int i = 0; i < (NT + 1) / 2; ++i) bw[i] = 0u;
@@ -382,10 +384,14 @@ __device__ __forceinline__ void layer16(Pipe& p, int nb1, int nb2, const h16x8 (
             f32x16 acc1 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
             f32x16 acc2 = acc1;
             if (NT > 1 && SAVE < 2) {                      // (the backward stages have no bias)
-                const unsigned bp = p.lds_base + p.bias_off + tt * 128 + (lane >> 5) * 16;
-                const f32x4 b0 = lds_ld4f(bp), b1 = lds_ld4f(bp + 32), b2 = lds_ld4f(bp + 64), b3 = lds_ld4f(bp + 96);
-                acc1 = f32x16{b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w,
-                              b2.x, b2.y, b2.z, b2.w, b3.x, b3.y, b3.z, b3.w};
+                if (t == 0) {
+                    const unsigned bp = p.lds_base + p.bias_off + tt * 128 + (lane >> 5) * 16;
+                    const f32x4 b0 = lds_ld4f(bp), b1 = lds_ld4f(bp + 32), b2 = lds_ld4f(bp + 64), b3 = lds_ld4f(bp + 96);
+                    acc1 = f32x16{b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w,
+                                  b2.x, b2.y, b2.z, b2.w, b3.x, b3.y, b3.z, b3.w};
+                } else {
+                    acc1 = nbias;                          // read during the previous tile (see below)
+                }
             }
             h16x8 qwh[PFK], qwl[PFK], qxh[PFK], qxl[PFK];
 #pragma unroll
@@ -425,6 +431,12 @@ __device__ __forceinline__ void layer16(Pipe& p, int nb1, int nb2, const h16x8 (
                 acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, xh, acc1, 0, 0, 0);
                 acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, xl, acc2, 0, 0, 0);
                 acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, xh, acc2, 0, 0, 0);
+                if (NT > 1 && SAVE < 2 && ks == NK - 1 && t + 1 < NT) {
+                    const unsigned bn = p.lds_base + p.bias_off + (tt + 1) * 128 + (lane >> 5) * 16;   // (tt + 1 == TPS: next slab's first)
+                    const f32x4 b0 = lds_ld4f(bn), b1 = lds_ld4f(bn + 32), b2 = lds_ld4f(bn + 64), b3 = lds_ld4f(bn + 96);
+                    nbias = f32x16{b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w,
+                                   b2.x, b2.y, b2.z, b2.w, b3.x, b3.y, b3.z, b3.w};
+                }
                 {   // DMA piece (gk - 1) of slab n+2 at slab-local k-step gk = tt NK + ks
                     constexpr int MAXP = (TPS * NK - 1) < 10 ? (TPS * NK - 1) : 10;
                     const int i = tt * NK + ks - 1;
