@@ -343,9 +343,16 @@ __device__ __forceinline__ void save_pair(SaveCtx& sc, uint32_t (&bw)[NW], int t
 //     96 cycles of one k-step's MFMAs);
 //   * the VALU epilogue of tile t-1 (8 pair-units) is spread over the k-steps of tile t,
 //     so it runs in the shadow of the MFMAs; only the last tile's epilogue is exposed.
-template <int NT, int TPS, int NKA, int NKB, bool RELU, int SAVE = 0, int NB, int NO>
-__device__ __forceinline__ void layer16(Pipe& p, int nb1, int nb2, const h16x8 (&bh)[NB], const h16x8 (&bl)[NB],
-                                        h16x8 (&oh)[NO], h16x8 (&ol)[NO], float (&last)[16], SaveCtx* sc = nullptr) {
+//   * PEND_IN / DEFER (inference): the epilogue of a layer's LAST tile has no next tile of its own layer to hide
+//     behind; with DEFER it is left pending in (pend1, pend2) and the next layer (PEND_IN) runs it inside its first
+//     tile, writing the last two fragments of its own input just before the k-steps that consume them.
+template <int NT, int TPS, int NKA, int NKB, bool RELU, int SAVE = 0, bool PEND_IN = false, bool DEFER = false,
+          int NB, int NO>
+__device__ __forceinline__ void layer16(Pipe& p, int nb1, int nb2, h16x8 (&bh)[NB], h16x8 (&bl)[NB],
+                                        h16x8 (&oh)[NO], h16x8 (&ol)[NO], float (&last)[16], SaveCtx* sc = nullptr,
+                                        f32x16* pend1 = nullptr, f32x16* pend2 = nullptr) {
+    static_assert(!(PEND_IN || DEFER) || SAVE == 0, "deferred epilogues exist in the inference form only");
+    static_assert(!PEND_IN || NKB >= 2, "a pending tile fills the last two hidden fragments");
     static_assert(NB >= (NKB > 0 ? NKB : 1) && NO >= 2 * NT && NT % TPS == 0, "bad layer shape");
     constexpr int NK = NKA + NKB;
     constexpr int NBLK = 2 * NK;             // blocks per tile
@@ -448,6 +455,14 @@ __device__ __forceinline__ void layer16(Pipe& p, int nb1, int nb2, const h16x8 (
                         }
                     }
                 }
+                if (PEND_IN && t == 0) {   // the previous layer's last tile: fragments NKB-2, NKB-1 of this layer's input
+#pragma unroll
+                    for (int i = 0; i < 8; ++i)
+                        if ((i * NK) / 8 == ks) {
+                            epi_pair<true>(*pend1, *pend2, i, bh[NKB - 2 + (i >> 2)], bl[NKB - 2 + (i >> 2)]);
+                            asm volatile("" : "+v"(bh[NKB - 2 + (i >> 2)]), "+v"(bl[NKB - 2 + (i >> 2)]));
+                        }
+                }
                 if (t > 0) {      // pending epilogue of tile t-1: pair i runs at k-step (i * NK) / 8
 #pragma unroll
                     for (int i = 0; i < 8; ++i)
@@ -502,6 +517,9 @@ __device__ __forceinline__ void layer16(Pipe& p, int nb1, int nb2, const h16x8 (
     if (NT == 1) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) last[r] = pacc1[r] + pacc2[r] * LO_INV;
+    } else if (DEFER) {
+        *pend1 = pacc1;
+        *pend2 = pacc2;
     } else {
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
@@ -753,29 +771,31 @@ __global__ __launch_bounds__(256) void canonical_f16x3_kernel(const float* __res
 
     h16x8 hA_h[16], hA_l[16], hB_h[16], hB_l[16];
     float last[16];
-    layer16<8, 4, 4, 0, true, SAVE ? 1 : 0>(p, CNL16_NB_MID, CNL16_NB_MID, hB_h, hB_l, hA_h, hA_l, last, &sc);   // (hB unused: NKB = 0)
+    f32x16 pend1, pend2;                          // inference: last-tile epilogues travel into the next layer
+    constexpr bool DF = !SAVE;
+    layer16<8, 4, 4, 0, true, SAVE ? 1 : 0, false, DF>(p, CNL16_NB_MID, CNL16_NB_MID, hB_h, hB_l, hA_h, hA_l, last, &sc, &pend1, &pend2);   // (hB unused: NKB = 0)
     if constexpr (SAVE) { sc.row += act_stride; sc.bits += bit_stride; }
 #pragma unroll 1
     for (int l = 1; l <= 4; ++l) {
         const int nb = l == 4 ? CNL16_NB_L5 : CNL16_NB_MID;
-        layer16<8, 1, 0, 16, true, SAVE ? 1 : 0>(p, nb, nb, hA_h, hA_l, hB_h, hB_l, last, &sc);
+        layer16<8, 1, 0, 16, true, SAVE ? 1 : 0, DF, DF>(p, nb, nb, hA_h, hA_l, hB_h, hB_l, last, &sc, &pend1, &pend2);
         if constexpr (SAVE) { sc.row += act_stride; sc.bits += bit_stride; }
 #pragma unroll
         for (int i = 0; i < 16; ++i) { hA_h[i] = hB_h[i]; hA_l[i] = hB_l[i]; }
     }
-    layer16<8, 1, 4, 16, true, SAVE ? 1 : 0>(p, CNL16_NB_MID, CNL16_NB_MID, hA_h, hA_l, hB_h, hB_l, last, &sc);   // skip layer
+    layer16<8, 1, 4, 16, true, SAVE ? 1 : 0, DF, DF>(p, CNL16_NB_MID, CNL16_NB_MID, hA_h, hA_l, hB_h, hB_l, last, &sc, &pend1, &pend2);   // skip layer
     if constexpr (SAVE) { sc.row += act_stride; sc.bits += bit_stride; }
 #pragma unroll
     for (int i = 0; i < 16; ++i) { hA_h[i] = hB_h[i]; hA_l[i] = hB_l[i]; }
 #pragma unroll 1
     for (int l = 6; l <= 7; ++l) {
-        layer16<8, 1, 0, 16, true, SAVE ? 1 : 0>(p, CNL16_NB_MID, l == 7 ? 0 : CNL16_NB_MID, hA_h, hA_l, hB_h, hB_l, last, &sc);
+        layer16<8, 1, 0, 16, true, SAVE ? 1 : 0, DF, DF>(p, CNL16_NB_MID, l == 7 ? 0 : CNL16_NB_MID, hA_h, hA_l, hB_h, hB_l, last, &sc, &pend1, &pend2);
         if constexpr (SAVE) { sc.row += act_stride; sc.bits += bit_stride; }
 #pragma unroll
         for (int i = 0; i < 16; ++i) { hA_h[i] = hB_h[i]; hA_l[i] = hB_l[i]; }
     }
     h16x8 dh[2], dl[2];
-    layer16<1, 1, 0, 16, false>(p, 0, 0, hA_h, hA_l, dh, dl, last);
+    layer16<1, 1, 0, 16, false, 0, DF, false>(p, 0, 0, hA_h, hA_l, dh, dl, last, nullptr, &pend1, &pend2);
     const float* ob = reinterpret_cast<const float*>(packed + CNL16_BIAS + CNL16_BIAS_LDS);   // head bias: scalar loads
     if (h == 0 && slot < P) raw[sample] = make_float4(last[0] + ob[0], last[1] + ob[1], last[2] + ob[2], last[3] + ob[3]);
 #ifdef HNRF_STAMP
