@@ -455,10 +455,11 @@ __device__ __forceinline__ void layer16(Pipe& p, int nb1, int nb2, h16x8 (&bh)[N
                         }
                     }
                 }
-                if (PEND_IN && t == 0) {   // the previous layer's last tile: fragments NKB-2, NKB-1 of this layer's input
+                if (PEND_IN && t == 0) {   // the previous layer's last tile: fragments NKB-2, NKB-1 of this layer's input,
+                                           // complete before the k-steps that read them (the last one at NK - 1)
 #pragma unroll
                     for (int i = 0; i < 8; ++i)
-                        if ((i * NK) / 8 == ks) {
+                        if ((i * (NK - 1)) / 8 == ks) {
                             epi_pair<true>(*pend1, *pend2, i, bh[NKB - 2 + (i >> 2)], bl[NKB - 2 + (i >> 2)]);
                             asm volatile("" : "+v"(bh[NKB - 2 + (i >> 2)]), "+v"(bl[NKB - 2 + (i >> 2)]));
                         }
