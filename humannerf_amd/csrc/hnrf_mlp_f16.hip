@@ -444,9 +444,10 @@ __device__ __forceinline__ void layer16(Pipe& p, int nb1, int nb2, h16x8 (&bh)[N
                     nbias = f32x16{b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w,
                                    b2.x, b2.y, b2.z, b2.w, b3.x, b3.y, b3.z, b3.w};
                 }
-                {   // DMA piece (gk - 1) of slab n+2 at slab-local k-step gk = tt NK + ks
+                {   // DMA piece gk of slab n+2 at slab-local k-step gk = tt NK + ks (from the slab's very first k-step:
+                    // every k-step of head start shortens the vmcnt wait at the end of the next slab)
                     constexpr int MAXP = (TPS * NK - 1) < 10 ? (TPS * NK - 1) : 10;
-                    const int i = tt * NK + ks - 1;
+                    const int i = tt * NK + ks;
                     if (i >= 0 && i < MAXP) {
                         if (s + 2 < NS) {                      // piece count known at compile time
                             if (i < NBLK * TPS / 4) dma_piece(dsrc + i * 4096, lane * 16, ddst + i * 4096);
@@ -635,7 +636,7 @@ __device__ __forceinline__ void layer16x2(Pipe& p, unsigned stash_per_wave, int 
                 }
                 {
                     constexpr int MAXP = (TPS * NK - 1) < 10 ? (TPS * NK - 1) : 10;
-                    const int i = tt * NK + ks - 1;
+                    const int i = tt * NK + ks;
                     if (i >= 0 && i < MAXP) {
                         if (s + 2 < NS) {
                             if (i < NBLK * TPS / 4) dma_piece(dsrc + i * 4096, lane * 16, ddst + i * 4096);
