@@ -74,7 +74,7 @@ def main():
     from humannerf_amd import scene
     from humannerf_amd.config import cfg
     from humannerf_amd.network import Network
-    from oracle.seeded import default_shapes, seeded_state      # weights only (same recipe as the fixtures)
+    from humannerf_amd.seeded import default_shapes, seeded_state      # seeded random-init weights (data recipe shared with the fixtures)
 
     cfg.perturb, cfg.N_samples, cfg.ignore_non_rigid_motions = 0., S, False
     # headline = the reference's full return signature (all 11 outputs of Network.forward materialised, 17 KB per

@@ -3,7 +3,7 @@ import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from humannerf_amd import ops
-from oracle.seeded import default_shapes, seeded_state
+from humannerf_amd.seeded import default_shapes, seeded_state
 dev = torch.device('cuda:0')
 st = seeded_state({k: v for k, v in default_shapes().items() if 'mlp' in k and 'decoder' not in k}, 0)
 T = lambda a: torch.from_numpy(a).to(dev)

@@ -6,7 +6,7 @@ from humannerf_amd import scene
 from humannerf_amd.config import cfg
 from humannerf_amd.network import Network
 from humannerf_amd.train import Trainer, image_loss, update_lr
-from oracle.seeded import default_shapes, seeded_state
+from humannerf_amd.seeded import default_shapes, seeded_state
 dev = torch.device('cuda:0')
 state = seeded_state(default_shapes(), 0)
 net = Network(); net.load_state_dict({k: torch.from_numpy(v) for k, v in state.items()}); net = net.to(dev).train()
