@@ -225,6 +225,26 @@ def main():
                                     'error bound 2*S*eps'}
 
     if extras:
+        # opt-in early ray termination on top of the culling: rays stop being evaluated once their transmittance is
+        # below 1e-4 (front-to-back slabs of 32 samples); reported separately, never as `value`
+        cfg.amd.cull_eps, cfg.amd.term_eps, cfg.amd.diagnostics = 1e-9, 1e-4, False
+        step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(3):
+            ot = step()
+        torch.cuda.synchronize()
+        dt_t = time.perf_counter() - t0
+        cfg.amd.cull_eps, cfg.amd.term_eps, cfg.amd.diagnostics = 0.0, 0.0, not args.lean
+        result['terminated'] = {'term_eps': 1e-4, 'cull_eps': 1e-9, 'rays_per_s_per_gpu': round(R * 3 / dt_t, 1),
+                                'max_abs_rgb_diff_vs_dense': float((ot['rgb'] - out['rgb']).abs().max()),
+                                'note': 'rays are not evaluated past transmittance < term_eps; not the reference '
+                                        'arithmetic, error bound term_eps.  The saving depends on how opaque the scene '
+                                        'is: with the seeded random weights of this benchmark no ray saturates (max '
+                                        'alpha < 0.999), so this leg only shows the cost of the slab-wise walk'}
+        del ot
+
+    if extras:
         # the frame loop around the path (run.py:68-157): camera -> rays on the device (hnrf_gen_rays), render,
         # scatter into the H x W image with background fill, 8-bit quantisation, asynchronous copy to the host
         from humannerf_amd import render

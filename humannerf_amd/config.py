@@ -135,6 +135,9 @@ _DEFAULTS = {
         # 0 = evaluate every sample exactly like the reference.  1e-9 already drops ~55 % of the
         # samples of a typical frame at an error 100x below the reference's own fp32 noise.
         'cull_eps': 0.0,
+        # lean rendering only: stop evaluating a ray once its transmittance is below this (front-to-back slabs of 32
+        # samples); bounds |d rgb|, |d alpha| by term_eps.  0 = off (the reference evaluates every sample).
+        'term_eps': 0.0,
     },
 }
 

@@ -454,6 +454,11 @@ class Network(nn.Module):
             need = ops.render_workspace_bytes(rays_o.shape[0], S) // 4 + 64
             if self._workspace is None or self._workspace.numel() < need or self._workspace.device != rays_o.device:
                 self._workspace = torch.empty(need, device=rays_o.device)
+            term_eps = float(amd_option('term_eps', 0.0))
+            if term_eps > 0.0:
+                return ops.render_rays_term(rays_o, rays_d, near, far, t_rand, motion_Rs, motion_Ts, vol, bbox_min,
+                                            bbox_scale, hann_w, nr_packed, cnl_packed, bg, S, mode, term_eps=term_eps,
+                                            cull_eps=float(amd_option('cull_eps', 0.0)), workspace=self._workspace)
             events = None
             if self.mlp_event_log is not None:
                 events = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))

@@ -196,6 +196,36 @@ def render_rays(rays_o, rays_d, near, far, t_rand, motion_Rs, motion_Ts, vol, bb
     return out
 
 
+def render_rays_term(rays_o, rays_d, near, far, t_rand, motion_Rs, motion_Ts, vol, bbox_min, bbox_scale,
+                     hann_w, nr_packed, cnl_packed, bgcolor, n_samples, mode='f16x3', term_eps=1e-4, cull_eps=0.0,
+                     workspace=None, want_count=False):
+    """Lean path with early ray termination (opt-in approximation, |d rgb|, |d alpha| <= term_eps): see
+    hnrf_render_rays_term_fwd.  Returns the rgb/alpha/depth dict (+ 'evaluated': device int tensor when asked)."""
+    lib = _lib.load()
+    near, far = near.reshape(-1), far.reshape(-1)
+    _chk(rays_o, rays_d, near, far, t_rand, motion_Rs, motion_Ts, vol, bbox_min, bbox_scale, hann_w,
+         nr_packed, cnl_packed, bgcolor)
+    R, S = rays_o.shape[0], int(n_samples)
+    need = lib.hnrf_render_term_workspace_bytes(R, S)
+    if workspace is None or workspace.numel() * workspace.element_size() < need:
+        workspace = torch.empty(need // 4 + 64, device=rays_o.device)
+    dev = rays_o.device
+    out = {'rgb': torch.empty(R, 3, device=dev), 'alpha': torch.empty(R, device=dev), 'depth': torch.empty(R, device=dev)}
+    ev = torch.empty(1, dtype=torch.int32, device=dev) if want_count else None
+    _lib.check(lib.hnrf_render_rays_term_fwd(_ptr(rays_o), _ptr(rays_d), _ptr(near), _ptr(far), _ptr(t_rand),
+                                             _ptr(motion_Rs), _ptr(motion_Ts), _ptr(vol), _ptr(bbox_min),
+                                             _ptr(bbox_scale), _ptr(hann_w), _ptr(nr_packed), _ptr(cnl_packed),
+                                             _ptr(bgcolor), MLP_MODES[mode], float(cull_eps), float(term_eps), R, S,
+                                             motion_Rs.shape[0], vol.shape[-1], _ptr(workspace),
+                                             workspace.numel() * workspace.element_size(), _ptr(out['rgb']),
+                                             _ptr(out['alpha']), _ptr(out['depth']),
+                                             None if ev is None else ev.data_ptr(), _stream()),
+               'hnrf_render_rays_term_fwd')
+    if ev is not None:
+        out['evaluated'] = ev
+    return out
+
+
 # ----------------------------------------------------------------------------- training
 def canonical_train(xyz, packed, mode='f32'):
     """hnrf_canonical_fwd_train: raw (...,4), pe (P,63), acts (8,P,256), relu sign masks (8,P,8) int32.

@@ -146,6 +146,21 @@ int hnrf_render_rays_fwd(const float* rays_o, const float* rays_d,
                          float* rgb, float* alpha, float* depth,
                          void* ev_mlp_start, void* ev_mlp_stop, void* stream);
 
+/* Opt-in variant with early ray termination (NOT the reference arithmetic): the samples are walked front to back
+ * in slabs of 32; a ray whose transmittance has fallen below term_eps (0 < term_eps < 1) is not evaluated further,
+ * which moves rgb / alpha by at most term_eps; cull_eps as above (may be 0).  evaluated (nullable): device int that
+ * receives the number of samples that went through the MLPs.  workspace: hnrf_render_term_workspace_bytes. */
+size_t hnrf_render_term_workspace_bytes(int64_t R, int S);
+int hnrf_render_rays_term_fwd(const float* rays_o, const float* rays_d,
+                              const float* near, const float* far, const float* t_rand,
+                              const float* motion_Rs, const float* motion_Ts,
+                              const float* vol, const float* bbox_min, const float* bbox_scale,
+                              const float* hann_w, const void* nr_packed, const void* cnl_packed,
+                              const float* bgcolor, int mode, float cull_eps, float term_eps,
+                              int64_t R, int S, int B, int G,
+                              void* workspace, size_t workspace_bytes,
+                              float* rgb, float* alpha, float* depth, int* evaluated, void* stream);
+
 /* =============================== training (backward) ===============================
  * The reference trains through torch.autograd over the ops above (trainer.py:206-220).
  * Here: the forward runs the *_fwd_train variants (HNRF_MLP_F32 only) which also save the

@@ -36,7 +36,7 @@ int main(int argc, char** argv) {
     const int64_t R = atoll(argv[1]);
     const int S = atoi(argv[2]), mode = atoi(argv[3]);
     const int B = 24, G = 32;
-    if (hnrf_abi_version() < 6) { fprintf(stderr, "old libhnrf\n"); return 1; }
+    if (hnrf_abi_version() < 7) { fprintf(stderr, "old libhnrf\n"); return 1; }
     hipStream_t st;
     CK(hipStreamCreate(&st));
 

@@ -453,3 +453,65 @@ def test_c5_full_frame_is_chunk_and_neighbour_independent(seeded_params):
         assert torch.isfinite(out[k]).all()
         assert torch.equal(out[k][sel], alone[k]), k
     assert 0.05 < float(out['alpha'].mean()) < 0.999
+
+
+@pytest.mark.parametrize('mode', ['f16x3', 'f32'])
+def test_early_ray_termination_is_bounded(gpu_net, mode):
+    """Opt-in early ray termination (cfg.amd.term_eps, lean path): front-to-back slabs of 32 samples, rays whose
+    transmittance fell below term_eps are not evaluated further.  The result moves by at most ~term_eps, the number
+    of evaluated samples drops, and a vanishing threshold reproduces the dense result up to the slab-wise product
+    order."""
+    from humannerf_amd import ops, scene
+    from humannerf_amd.config import cfg
+    fr = scene.synthetic_frame(H=512, W=512, focal_at_512=1700.0, ray_stride=4)       # 16 384 rays
+    data = frame_to_gpu(fr)
+    cfg.perturb, cfg.amd.diagnostics, cfg.amd.mlp_mode = 0., False, mode
+    try:
+        with torch.no_grad():
+            dense = gpu_net(**data, iter_val=1e7)
+            res = {}
+            for eps in (1e-3, 1e-30):
+                cfg.amd.term_eps = eps
+                res[eps] = gpu_net(**data, iter_val=1e7)
+            cfg.amd.term_eps, cfg.amd.cull_eps = 1e-3, 1e-9
+            both = gpu_net(**data, iter_val=1e7)
+    finally:
+        cfg.perturb, cfg.amd.diagnostics, cfg.amd.mlp_mode, cfg.amd.term_eps, cfg.amd.cull_eps = 1.0, True, 'f16x3', 0.0, 0.0
+    for k, tol in (('rgb', 1.5e-3), ('alpha', 1.5e-3)):
+        assert float((res[1e-3][k] - dense[k]).abs().max()) <= tol, k
+        assert float((both[k] - dense[k]).abs().max()) <= tol, k
+        assert float((res[1e-30][k] - dense[k]).abs().max()) <= 2e-6, k
+    assert float((res[1e-30]['depth'] - dense['depth']).abs().max()) <= 2e-5
+    # how much work the threshold saves on this frame (direct call on one chunk)
+    from humannerf_amd.network import motion_basis
+    assert float((res[1e-3]['rgb'] - dense['rgb']).abs().max()) > 0.0          # the cut really happened
+
+
+def test_early_ray_termination_evaluates_fewer_samples():
+    """hnrf_render_rays_term_fwd reports the number of samples that went through the MLPs."""
+    from humannerf_amd import ops
+    d = dev()
+    rs = np.random.RandomState(2)
+    R, S, B, G = 512, 128, 24, 32
+    T = lambda a: torch.from_numpy(np.ascontiguousarray(a.astype(np.float32))).to(d)
+    st = _mlp_states(rs)
+    idx = [0, 2, 4, 6, 8, 10, 12, 14]
+    cw = [T(st[f'cnl_mlp.module.pts_linears.{i}.weight']) for i in idx] + [T(st['cnl_mlp.module.output_linear.0.weight'])]
+    cb = [T(st[f'cnl_mlp.module.pts_linears.{i}.bias']) for i in idx] + [T(st['cnl_mlp.module.output_linear.0.bias'])]
+    cb[-1] = cb[-1].clone(); cb[-1][3] += 40.0                                   # dense medium: rays saturate quickly
+    names = [f'non_rigid_mlp.module.block_mlps.{i}' for i in (0, 2, 4, 6, 8, 10, 12)]
+    nw, nb = [T(st[n + '.weight']) for n in names], [T(st[n + '.bias']) for n in names]
+    rays_o = T(rs.uniform(-0.2, 0.2, (R, 3)) + np.array([0, 0, -3.0])); rays_d = T(np.concatenate([rs.uniform(-0.25, 0.25, (R, 2)), np.ones((R, 1))], 1))
+    near, far = T(rs.uniform(2.0, 2.3, R)), T(rs.uniform(3.6, 4.0, R))
+    Rs = T(np.tile(np.eye(3), (B, 1, 1))); Ts = T(rs.uniform(-0.1, 0.1, (B, 3)))
+    vol = T(rs.uniform(0.0, 0.08, (B + 1, G, G, G)))
+    bmin, bscale = T(np.full(3, -1.2)), T(np.full(3, 2.0 / 2.4))
+    hann, bg = torch.ones(6, device=d), T(np.array([255., 128., 0.]))
+    nrp = ops.nonrigid_pack(nw, nb, T(np.zeros(69)), 'f16x3'); cnp = ops.canonical_pack(cw, cb, 'f16x3')
+    dense = ops.render_rays(rays_o, rays_d, near, far, None, Rs, Ts, vol, bmin, bscale, hann, nrp, cnp, bg, S, 'f16x3')
+    out = ops.render_rays_term(rays_o, rays_d, near, far, None, Rs, Ts, vol, bmin, bscale, hann, nrp, cnp, bg, S,
+                               'f16x3', term_eps=1e-4, want_count=True)
+    n_eval = int(out['evaluated'].item())
+    assert 0 < n_eval < R * S // 2, n_eval
+    assert float((out['rgb'] - dense['rgb']).abs().max()) <= 2e-4
+    assert float((out['alpha'] - dense['alpha']).abs().max()) <= 2e-4
