@@ -35,7 +35,27 @@ H = W = 512
 S = 128
 CNL_MAC_PER_SAMPLE = 492032
 NR_MAC_PER_SAMPLE = 100352           # row a11
+PMC_FILE = 'r01_pmc_canonical.json'
 PEAK_TFLOPS = {'f32': 157.3, 'f16x3': 2500.0 / 3.0}   # MI355X_MICROARCH.md; f16x3 issues 3 f16 MFMAs per fp32-equivalent MAC
+
+
+def launch_ranks(n):
+    """Start ``n`` copies of this script, one per GPU (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* like
+    torch.distributed.run sets them), wait for all of them, return the worst exit code.  Rank 0 prints the JSON line
+    on the stdout it inherits."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY='0')
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    codes = [p.wait() for p in procs]
+    return max(abs(c) for c in codes)
 
 
 def main():
@@ -53,10 +73,14 @@ def main():
                          'so that a rocprofv3 --stats average covers exactly the launches behind `roofline`')
     args = ap.parse_args()
 
+    if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
+        # plain `python bench.py --gpus N`: this process becomes the launcher.  It has not touched the GPU (importing
+        # torch does not), starts one fresh process per GPU with the torchrun environment and relays rank 0's line.
+        sys.exit(launch_ranks(args.gpus))
     rank = int(os.environ.get('RANK', 0))
     local_rank = int(os.environ.get('LOCAL_RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
-    assert world == args.gpus or world == 1, (world, args.gpus)
+    assert world == args.gpus, 'WORLD_SIZE=%d but --gpus %d' % (world, args.gpus)
     assert torch.cuda.is_available(), 'bench.py needs an MI355X'
     if 'HNRF_BENCH_DEVICE' in os.environ:          # rehearsal of the N-rank path on a 1-GPU box (with gloo)
         local_rank = int(os.environ['HNRF_BENCH_DEVICE'])
@@ -130,8 +154,8 @@ def main():
     flop_per_launch = 2.0 * CNL_MAC_PER_SAMPLE * samples_per_launch
     avg_s = float(np.mean(k_ms)) * 1e-3
     achieved = flop_per_launch / avg_s / 1e12
-    traffic = None
-    pmc = os.path.join(ROOT, 'profiles', 'r01_pmc_canonical.json')
+    traffic, traffic_source = None, None
+    pmc = os.path.join(ROOT, 'profiles', PMC_FILE)
     if os.path.isfile(pmc):
         # measured offline (two separate --pmc passes, FETCH_SIZE doubled per the gfx950 correction);
         # committed under profiles/ because PMC counters cannot be read from inside this process
@@ -139,9 +163,10 @@ def main():
             rec = json.load(f)
         if rec.get('kernel') == 'canonical_%s_kernel' % args.mode and rec.get('samples_per_launch') == int(samples_per_launch):
             traffic = rec.get('hbm_bytes_per_launch')
+            traffic_source = 'profiles/' + PMC_FILE + ' (rocprofv3 --pmc passes of this command, not read in this run)'
     roofline = {'bound': 'mfma', 'kernel': 'canonical_%s_kernel' % args.mode, 'achieved': round(achieved, 2),
                 'peak': PEAK_TFLOPS[args.mode], 'unit': 'TFLOP/s', 'frac': round(achieved / PEAK_TFLOPS[args.mode], 4),
-                'traffic': traffic, 'launches': launches, 'avg_launch_ms': round(avg_s * 1e3, 4),
+                'traffic': traffic, 'traffic_source': traffic_source, 'launches': launches, 'avg_launch_ms': round(avg_s * 1e3, 4),
                 'flop_per_launch': flop_per_launch,
                 'kernel_share_of_step': round(float(np.sum(k_ms)) * 1e-3 / elapsed, 4)}
     if args.mode == 'f16x3':
@@ -279,7 +304,7 @@ def main():
         tb['rays'] = data['rays'][:, idx].contiguous()
         tb['near'], tb['far'] = data['near'][idx].contiguous(), data['far'][idx].contiguous()
         tb['target_rgbs'] = torch.from_numpy(np.random.RandomState(3 + rank).rand(idx.numel(), 3).astype(np.float32)).to(dev)
-        trainer = Trainer(net, world_size=world)
+        trainer = Trainer(net, world_size=world, logdir=None)
         for _ in range(3):
             trainer.train_step(tb)               # warm-up (allocator growth, MIOpen solution search for the decoder)
         torch.cuda.synchronize()

@@ -40,32 +40,45 @@ def _weight_grads(dZ, acts, pe, dY, weights, skip_layer, skip_order, amax=None, 
 
 
 class RenderRays(torch.autograd.Function):
-    """rgb, alpha, depth = RenderRays.apply(consts..., motion_Rs, motion_Ts, vol, *mlp_params)"""
+    """rgb, alpha, depth[, 8 diagnostic outputs] = RenderRays.apply(consts..., motion_Rs, motion_Ts, vol, *mlp_params)
+
+    With ``diag`` the other keys of the reference's return dict (network.py:776-789) come out too, as
+    non-differentiable tensors, in OUTPUT_KEYS order."""
+
+    OUTPUT_KEYS = ('rgb', 'alpha', 'depth', 'weights_on_rays', 'rgb_on_rays', 'cnl_xyz', 'cnl_rgb', 'cnl_weight',
+                   'xyz_on_rays', 'backward_motion_weights', 'offsets')
 
     @staticmethod
     def forward(ctx, rays_o, rays_d, near, far, t_rand, bbox_min, bbox_scale, hann_w, cond, bg, n_samples,
-                use_nonrigid, motion_Rs, motion_Ts, vol, *params):
+                use_nonrigid, diag, motion_Rs, motion_Ts, vol, *params):
         nr_w, nr_b = list(params[0:7]), list(params[7:14])
         cn_w, cn_b = list(params[14:23]), list(params[23:32])
         motion_Rs, motion_Ts, vol = motion_Rs.contiguous(), motion_Ts.contiguous(), vol.contiguous()
-        z, x_skel, mask, _ = ops.sample_warp(rays_o, rays_d, near, far, t_rand, motion_Rs, motion_Ts, vol, bbox_min,
-                                             bbox_scale, n_samples, want_bmw=False)
+        z, x_skel, mask, bmw = ops.sample_warp(rays_o, rays_d, near, far, t_rand, motion_Rs, motion_Ts, vol, bbox_min,
+                                               bbox_scale, n_samples, want_bmw=bool(diag))
         mode = amd_option('train_mlp_mode', 'f16x3')
         if use_nonrigid:
             nr_packed = ops.nonrigid_pack(nr_w, nr_b, cond, mode)
-            xyz, _, pe_n, acts_n, bits_n = ops.nonrigid_train(x_skel, hann_w, nr_packed, mode)
+            xyz, offsets, pe_n, acts_n, bits_n = ops.nonrigid_train(x_skel, hann_w, nr_packed, mode)
         else:
             xyz, pe_n, acts_n, bits_n = x_skel, None, None, None
+            offsets = torch.zeros_like(x_skel) if diag else None            # network.py:276-277
         cn_packed = ops.canonical_pack(cn_w, cn_b, mode)
         raw, pe_c, acts_c, bits_c = ops.canonical_train(xyz, cn_packed, mode)
-        out = ops.composite(raw, mask, z, rays_d, None, bg, diagnostics=False)
+        out = ops.composite(raw, mask, z, rays_d, xyz if diag else None, bg, diagnostics=bool(diag))
         ctx.use_nonrigid = use_nonrigid
+        ctx.n_out = 11 if diag else 3
         ctx.save_for_backward(rays_o, rays_d, z, x_skel, mask, xyz, raw, pe_c, acts_c, pe_n, acts_n, motion_Rs,
                               motion_Ts, vol, bbox_min, bbox_scale, hann_w, cond, bg, bits_c, bits_n, *nr_w, *cn_w)
-        return out['rgb'], out['alpha'], out['depth']
+        if not diag:
+            return out['rgb'], out['alpha'], out['depth']
+        out.update(xyz_on_rays=xyz.view_as(x_skel).clone(), backward_motion_weights=bmw, offsets=offsets)
+        extra = tuple(out[k] for k in RenderRays.OUTPUT_KEYS[3:])
+        ctx.mark_non_differentiable(*extra)
+        return (out['rgb'], out['alpha'], out['depth']) + extra
 
     @staticmethod
-    def backward(ctx, g_rgb, g_alpha, g_depth):
+    def backward(ctx, g_rgb, g_alpha, g_depth, *_unused):
         (rays_o, rays_d, z, x_skel, mask, xyz, raw, pe_c, acts_c, pe_n, acts_n, motion_Rs, motion_Ts, vol, bbox_min,
          bbox_scale, hann_w, cond, bg, bits_c, bits_n) = ctx.saved_tensors[:21]
         nr_w = list(ctx.saved_tensors[21:28])
@@ -94,4 +107,4 @@ class RenderRays(torch.autograd.Function):
             d_x_skel = d_xyz
         d_vol, d_Rs, d_Ts = ops.sample_warp_bwd(rays_o, rays_d, z, motion_Rs, motion_Ts, vol, bbox_min, bbox_scale,
                                                 x_skel, mask, d_x_skel.view_as(x_skel).contiguous(), d_mask)
-        return (None,) * 12 + (d_Rs, d_Ts, d_vol, *gWn, *gbn, *gWc, *gbc)
+        return (None,) * 13 + (d_Rs, d_Ts, d_vol, *gWn, *gbn, *gWc, *gbc)

@@ -118,7 +118,7 @@ _DEFAULTS = {
         # parity tests as 'f32' = v_mfma_f32_32x32x2_f32 (bitwise an fp32 fma chain),
         # at 3x the speed.
         'mlp_mode': 'f16x3',
-        # arithmetic of the activation-saving training forward (the backward kernels are fp32 MFMA either way)
+        # arithmetic of the activation-saving training forward ('f32' | 'f16x3')
         'train_mlp_mode': 'f16x3',
         # arithmetic of the weight-gradient kernel for the matrix-shaped layers ('f32' | 'f16x3')
         'train_dw_mode': 'f16x3',
@@ -138,6 +138,10 @@ _DEFAULTS = {
         # lean rendering only: stop evaluating a ray once its transmittance is below this (front-to-back slabs of 32
         # samples); bounds |d rgb|, |d alpha| by term_eps.  0 = off (the reference evaluates every sample).
         'term_eps': 0.0,
+        # multi-GPU training: 'volume' = average the 3.3 MB weight-volume gradient in front of the decoder backward (the
+        # decoder's 254 MB of gradients never travel; needs the same priors on every rank, verified at run time),
+        # 'full' = plain all-reduce of every gradient
+        'ddp_reduce': 'volume',
     },
 }
 

@@ -4,9 +4,8 @@
 //   K1' LBS-warp backward    -- d x_skel, d fg_mask -> d volume (atomics), d motion_Rs, d motion_Ts
 // They restate what torch.autograd derives for the reference's forward ops
 // (network.py:355-388, fourier.py / hannw_fourier.py embed, network.py:392-444 incl. the
-// grid_sample gradient w.r.t. both the volume and the sampling position).  The MLP GEMM
-// backward itself (dW = dZ^T X, dX = dZ W) runs as plain library GEMMs on the activation
-// matrices saved by hnrf_*_fwd_train.
+// grid_sample gradient w.r.t. both the volume and the sampling position).  The MLP
+// backward itself (dX chains, dW = dZ^T X) is in hnrf_mlp_bwd.hip / hnrf_mlp_f16.hip.
 #include "hnrf_common.h"
 
 namespace hnrf {

@@ -272,14 +272,56 @@ def _versions(params):
 
 
 # --------------------------------------------------------------------------- network
+def _node(root, path, default=None):
+    cur = root
+    for part in path.split('.'):
+        if cur is None or not hasattr(cur, 'get'):
+            return default
+        cur = cur.get(part, None)
+    return default if cur is None else cur
+
+
+# every switch of the reference's Network.__init__ / CanonicalMLP / NonRigidMotionMLP constructors that selects a
+# branch this build does not have (network.py:36-159, mlp_rgb_sigma.py:14-130, mlp_offset.py:9-71), with the only
+# value that is built.  Module paths are compared by their last component.
+_BUILT_BRANCHES = (
+    ('non_rigid_motion_model', 'mlp'),
+    ('canonical_mlp.view_dir', False), ('canonical_mlp.pose_color', 'wo'), ('canonical_mlp.multihead.enable', False),
+    ('canonical_mlp.mlp_depth_plus', 0), ('canonical_mlp.last_linear_scale', 1), ('canonical_mlp.i_embed', 0),
+    ('canonical_mlp.time_input', False), ('canonical_mlp.module', 'mlp_rgb_sigma'),
+    ('non_rigid_motion_mlp.mlp_depth_plus', 0), ('non_rigid_motion_mlp.last_linear_scale', 1),
+    ('non_rigid_motion_mlp.i_embed', 0), ('non_rigid_motion_mlp.time_input', False),
+    ('non_rigid_motion_mlp.pose_input', True), ('non_rigid_motion_mlp.multihead.enable', False),
+    ('non_rigid_motion_mlp.module', 'mlp_offset'),
+    ('rgb_history.last_num', 0), ('posevec.type', 'axis_angle'), ('condition_code.type', 'global'),
+    ('embedder.module', 'fourier'), ('non_rigid_embedder.module', 'hannw_fourier'),
+    ('mweight_volume.module', 'deconv_vol_decoder'), ('pose_decoder.module', 'mlp_delta_body_pose'),
+)
+
+
+def check_config_is_built(config):
+    """Raise unless ``config`` selects exactly the default-config branches of the reference network.  A checkpoint
+    trained with any other setting (e.g. ``mlp_depth_plus: 2``) has extra / different tensors that a
+    non-strict ``load_state_dict`` would drop silently, and the render would be wrong without an error."""
+    bad = []
+    for path, want in _BUILT_BRANCHES:
+        have = _node(config, path, want)
+        if path.endswith('.module'):
+            have = str(have).split('.')[-1]
+        if isinstance(want, bool):
+            have = bool(have)
+        if have != want:
+            bad.append('%s = %r (built: %r)' % (path, have, want))
+    if bad:
+        raise NotImplementedError('configuration selects branches outside the hot path this build implements '
+                                  '(SURVEY.md section 2.1): ' + '; '.join(bad))
+
+
 class Network(nn.Module):
     def __init__(self):
         super().__init__()
-        if cfg.get('non_rigid_motion_model', 'mlp') != 'mlp':
-            raise NotImplementedError('non_rigid_motion_model != mlp is outside the hot path (SURVEY.md section 2.1 #4)')
+        check_config_is_built(cfg)
         cm, nr = cfg.canonical_mlp, cfg.non_rigid_motion_mlp
-        if cm.get('view_dir', False) or cm.get('pose_color', 'wo') != 'wo' or cm.get('multihead', {}).get('enable', False):
-            raise NotImplementedError('only the default canonical MLP branch is built')
         self.total_bones = cfg.total_bones
 
         self.mweight_vol_decoder = MotionWeightVolumeDecoder(
@@ -299,6 +341,9 @@ class Network(nn.Module):
         self._nr_pack_buf = None
         self._vol_cache = None    # (key, priors, volume)
         self._workspace = None
+        # set by train.Trainer when world_size > 1: dist.GradientSync whose volume_hook averages the weight-volume
+        # gradient over the ranks in front of the decoder backward
+        self.grad_sync = None
         # set to a list to collect (start, stop) torch.cuda.Event pairs recorded around
         # every canonical-MLP launch (bench.py roofline)
         self.mlp_event_log = None
@@ -373,6 +418,8 @@ class Network(nn.Module):
         motion_Rs, motion_Ts = motion_basis(dst_Rs, dst_Ts, cnl_gtfms)
         vol = self._weight_volume(priors)
         self.motion_weights_vol = vol
+        if train_path and self.grad_sync is not None:
+            vol = self.grad_sync.volume_hook(vol, priors)
 
         mode = self._mlp_mode()
         nr_packed, cnl_packed, hann_w = None, None, None
@@ -418,7 +465,8 @@ class Network(nn.Module):
             if train_path:
                 chunks.append(self._render_rays_train(rays_o[sl], rays_d[sl], near[sl], far[sl],
                                                       None if t_rand is None else t_rand[sl], motion_Rs, motion_Ts,
-                                                      vol, bbox_min, bbox_scale, hann_w, cond, bg, S, not ignore_nr))
+                                                      vol, bbox_min, bbox_scale, hann_w, cond, bg, S, not ignore_nr,
+                                                      diag))
                 continue
             chunks.append(self._render_rays(rays_o[sl], rays_d[sl], near[sl], far[sl],
                                             None if t_rand is None else t_rand[sl],
@@ -433,28 +481,28 @@ class Network(nn.Module):
         return {k: v.reshape(lead + list(v.shape[1:])) for k, v in out.items()}
 
     def _render_rays_train(self, rays_o, rays_d, near, far, t_rand, motion_Rs, motion_Ts, vol, bbox_min, bbox_scale,
-                           hann_w, cond, bg, S, use_nonrigid):
-        """Differentiable chunk: autograd.RenderRays (fp32 MFMA kernels + saved activations).  Only the
-        three outputs the trainer's loss reads are produced (trainer.py:121)."""
+                           hann_w, cond, bg, S, use_nonrigid, diag):
+        """Differentiable chunk: autograd.RenderRays (activation-saving MLP kernels).  rgb / alpha / depth carry
+        gradient (the trainer's loss reads rgb, trainer.py:121); with ``cfg.amd.diagnostics`` the other eight keys of
+        the reference's return dict (network.py:776-789) are returned too, detached."""
         nr = self.non_rigid_mlp.module.linears()
         cn = self.cnl_mlp.module.linears()
         if hann_w is None:
             hann_w = torch.ones(6, device=rays_o.device)
         params = [l.weight for l in nr] + [l.bias for l in nr] + [l.weight for l in cn] + [l.bias for l in cn]
-        rgb, alpha, depth = RenderRays.apply(rays_o, rays_d, near, far, t_rand, bbox_min, bbox_scale, hann_w,
-                                             cond.detach().contiguous(), bg, S, use_nonrigid, motion_Rs, motion_Ts,
-                                             vol, *params)
-        return {'rgb': rgb, 'alpha': alpha, 'depth': depth}
+        res = RenderRays.apply(rays_o, rays_d, near, far, t_rand, bbox_min, bbox_scale, hann_w,
+                               cond.detach().contiguous(), bg, S, use_nonrigid, diag, motion_Rs, motion_Ts, vol, *params)
+        return dict(zip(RenderRays.OUTPUT_KEYS if diag else RenderRays.OUTPUT_KEYS[:3], res))
 
     def _render_rays(self, rays_o, rays_d, near, far, t_rand, motion_Rs, motion_Ts, vol, bbox_min, bbox_scale,
                      hann_w, nr_packed, cnl_packed, bg, S, mode, diag, dst=None):
         """network.py:474-602 for one ray chunk.  ``dst``: this chunk's row range of the whole-frame output buffers
         (full-signature path), written in place."""
         if not diag:
-            need = ops.render_workspace_bytes(rays_o.shape[0], S) // 4 + 64
+            term_eps = float(amd_option('term_eps', 0.0))
+            need = (ops.render_term_workspace_bytes if term_eps > 0.0 else ops.render_workspace_bytes)(rays_o.shape[0], S) // 4 + 64
             if self._workspace is None or self._workspace.numel() < need or self._workspace.device != rays_o.device:
                 self._workspace = torch.empty(need, device=rays_o.device)
-            term_eps = float(amd_option('term_eps', 0.0))
             if term_eps > 0.0:
                 return ops.render_rays_term(rays_o, rays_d, near, far, t_rand, motion_Rs, motion_Ts, vol, bbox_min,
                                             bbox_scale, hann_w, nr_packed, cnl_packed, bg, S, mode, term_eps=term_eps,

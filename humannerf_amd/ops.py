@@ -159,6 +159,10 @@ def render_workspace_bytes(R, S):
     return _lib.load().hnrf_render_workspace_bytes(int(R), int(S))
 
 
+def render_term_workspace_bytes(R, S):
+    return _lib.load().hnrf_render_term_workspace_bytes(int(R), int(S))
+
+
 def render_rays(rays_o, rays_d, near, far, t_rand, motion_Rs, motion_Ts, vol, bbox_min, bbox_scale,
                 hann_w, nr_packed, cnl_packed, bgcolor, n_samples, mode='f32', workspace=None, out=None,
                 mlp_events=None, cull_eps=0.0):

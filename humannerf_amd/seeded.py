@@ -64,6 +64,19 @@ def seeded_state(shapes, seed=0):
     return out
 
 
+def with_density(state, bias_delta=0.0, gain=1.0):
+    """Variant of a seeded state with a denser (or thinner) medium: the sigma row of the canonical head scaled by
+    ``gain`` and its bias moved by ``bias_delta``, in float32 on the float32 base tensors (so that the fixture
+    generator and the tests derive bit-identical weights).  Every other tensor is shared with ``state``."""
+    out = dict(state)
+    w = state['cnl_mlp.module.output_linear.0.weight'].copy()
+    b = state['cnl_mlp.module.output_linear.0.bias'].copy()
+    w[3] = w[3] * np.float32(gain)
+    b[3] = b[3] + np.float32(bias_delta)
+    out['cnl_mlp.module.output_linear.0.weight'], out['cnl_mlp.module.output_linear.0.bias'] = w, b
+    return out
+
+
 def default_shapes(volume_size=32, total_bones=24):
     """Parameter names/shapes of the reference Network in its default config
     (SURVEY.md section 5 key-name contract; Appendix A.4 census = 64 417 381 at 32^3)."""

@@ -1,32 +1,82 @@
-"""Training step around the hot path ("next" row).
+"""Training step and loop around the hot path ("next" row).
 
 Mirrors what the reference's trainer does per iteration (core/train/trainers/
 human_nerf/trainer.py:186-255), restated for one-process-per-GPU data parallelism:
 
   * optimizer: Adam(betas=(0.9, 0.999)), one param group per tensor, learning rate
-    routed by name substring from cfg.train.lr_* (optimizers/human_nerf/optimizer.py:12-43);
+    routed by name substring from cfg.train.lr_* (optimizers/human_nerf/optimizer.py:12-43).
+    ``GroupedAdam`` keeps exactly that group structure (``state_dict()`` is interchangeable with the
+    reference's optimizer checkpoints) but updates all groups that share hyper-parameters in ONE
+    multi-tensor launch -- two launches per step (5e-4 and 5e-5) instead of 56;
   * learning-rate schedule: base * 0.1 ** (iter / (lrate_decay * 1000))
-    (lr_updaters/exp_decay.py:7-16);
+    (lr_updaters/exp_decay.py:7-16), applied after the step like trainer.py:253;
   * loss: patches rebuilt from the rendered rays by mask / div indices with background fill
     (trainer.py:28-37), 0.2 * MSE (+ 1.0 * LPIPS in the reference; the VGG trunk cannot be
-    fetched offline, so LPIPS is a pluggable callable that defaults to absent);
-  * every rank renders its own frame; gradients are mean-all-reduced over RCCL in two flat
-    buckets (humannerf_amd/dist.py) before the optimizer step.  The reference's
+    fetched offline, so LPIPS is a pluggable callable; without it the objective is MSE-ONLY and
+    the trainer says so once -- ``Trainer.objective``);
+  * every rank renders its own frame; gradients are averaged over RCCL by ``dist.GradientSync``
+    (volume-gradient all-reduce in front of the decoder backward + one 3.3 MB bucket).  The reference's
     nn.DataParallel uses ONE frame per step whatever the GPU count: with N ranks the
     effective batch here is N frames (stated with every iters/s number);
-  * checkpoint dict {'iter', 'network', 'optimizer'} (trainer.py:356-364).
+  * checkpoints: dict {'iter', 'network', 'optimizer'} in ``<logdir>/<name>.tar`` (trainer.py:356-377),
+    read back with ``weights_only=True``; 'latest' every cfg.train.save_checkpt_interval iterations and at the
+    first one, 'iter_N' every cfg.train.save_model_interval when cfg.save_all (trainer.py:246-251);
+  * progress renders at iterations {start, 100, 300, 1000, 2500} and every cfg.progress.dump_interval
+    (trainer.py:240-243, 271-350) through a caller-supplied callable.
 """
+import os
+import warnings
+
 import torch
 
 from . import dist as hdist
-from .config import cfg
+from .config import cfg, amd_option
 
 
 def customized_lr_names():
     return [k[3:] for k in cfg.train.keys() if k.startswith('lr_')]
 
 
+class GroupedAdam(torch.optim.Adam):
+    """torch.optim.Adam with the reference's one-group-per-tensor layout, stepped with one fused multi-tensor
+    launch per distinct (lr, betas, eps, weight_decay) instead of one per group.  Same update rule as
+    torch's fused Adam (bias-corrected, eps outside the square root); parameters whose grad is None are skipped and
+    their step counters do not advance."""
+
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
+        super().__init__(params, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, fused=True)
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        assert closure is None
+        classes = {}
+        for group in self.param_groups:
+            assert not group['amsgrad'] and not group['maximize']
+            key = (float(group['lr']), tuple(group['betas']), float(group['eps']), float(group['weight_decay']))
+            cls = classes.setdefault(key, ([], [], [], [], []))
+            for p in group['params']:
+                if p.grad is None:
+                    continue
+                st = self.state[p]
+                if len(st) == 0:
+                    st['step'] = torch.zeros((), dtype=torch.float32, device=p.device)
+                    st['exp_avg'] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                    st['exp_avg_sq'] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                cls[0].append(p)
+                cls[1].append(p.grad)
+                cls[2].append(st['exp_avg'])
+                cls[3].append(st['exp_avg_sq'])
+                cls[4].append(st['step'])
+        for (lr, (b1, b2), eps, wd), (ps, gs, m, v, steps) in classes.items():
+            if not ps:
+                continue
+            torch._foreach_add_(steps, 1)
+            torch._fused_adam_(ps, gs, m, v, [], steps, amsgrad=False, lr=lr, beta1=b1, beta2=b2, weight_decay=wd,
+                               eps=eps, maximize=False, grad_scale=None, found_inf=None)
+
+
 def build_optimizer(network):
+    """optimizers/human_nerf/optimizer.py:12-43."""
     groups = []
     names = customized_lr_names()
     for key, value in network.named_parameters():
@@ -39,13 +89,11 @@ def build_optimizer(network):
             groups.append({'params': [value], 'name': key})
     if cfg.train.optimizer != 'adam':
         raise ValueError('Unsupported optimizer ' + str(cfg.train.optimizer))
-    # same per-parameter groups as the reference (optimizer checkpoints stay interchangeable); on the GPU the
-    # update of each group is one fused kernel instead of torch's default chain of foreach kernels
-    fused = all(g['params'][0].is_cuda for g in groups)
-    return torch.optim.Adam(groups, lr=cfg.train.lr, betas=(0.9, 0.999), fused=fused)
+    return GroupedAdam(groups, lr=cfg.train.lr, betas=(0.9, 0.999))
 
 
 def update_lr(optimizer, iter_step):
+    """lr_updaters/exp_decay.py:7-16."""
     decay = 0.1 ** (iter_step / (cfg.train.lrate_decay * 1000))
     for group in optimizer.param_groups:
         base = cfg.train.get('lr_' + str(group['name']), cfg.train.lr)
@@ -53,7 +101,7 @@ def update_lr(optimizer, iter_step):
 
 
 def unpack_patches(rgbs, patch_masks, bgcolor, targets, div_indices):
-    """(sum_rays, 3) rendered colours -> (N_patch, H, W, 3) images, background elsewhere."""
+    """(sum_rays, 3) rendered colours -> (N_patch, H, W, 3) images, background elsewhere (trainer.py:28-37)."""
     n_patch = len(div_indices) - 1
     assert patch_masks.shape[0] == n_patch and targets.shape[0] == n_patch
     imgs = bgcolor.expand(targets.shape).clone()
@@ -63,7 +111,8 @@ def unpack_patches(rgbs, patch_masks, bgcolor, targets, div_indices):
 
 
 def image_loss(rgb, target, lpips_fn=None):
-    """sum_k lossweights[k] * loss_k over the weights > 0 (trainer.py:97-175, single-head branch)."""
+    """sum_k lossweights[k] * loss_k over the weights > 0 (trainer.py:97-175, single-head branch).  The LPIPS term
+    is left out when no ``lpips_fn`` is given (see Trainer.objective)."""
     weights = {k: v for k, v in cfg.train.lossweights.items() if v > 0}
     total, parts = 0.0, {}
     if 'mse' in weights:
@@ -78,16 +127,32 @@ def image_loss(rgb, target, lpips_fn=None):
     return total, parts
 
 
+PROGRESS_ITERS = (100, 300, 1000, 2500)          # trainer.py:240
+
+
 class Trainer:
-    def __init__(self, network, optimizer=None, lpips_fn=None, world_size=1):
+    def __init__(self, network, optimizer=None, lpips_fn=None, world_size=1, process_group=None, logdir=None):
         self.network = network.deploy_mlps_to_secondary_gpus()
         self.optimizer = optimizer if optimizer is not None else build_optimizer(network)
         self.lpips_fn = lpips_fn
-        self.world_size = world_size
+        self.world_size = int(world_size)
+        self.logdir = logdir if logdir is not None else cfg.get('logdir', None)
+        self.grad_sync = hdist.GradientSync(network, self.world_size, group=process_group,
+                                            mode=amd_option('ddp_reduce', 'volume'))
+        network.grad_sync = self.grad_sync if self.world_size > 1 else None
+        weights = {k: v for k, v in cfg.train.lossweights.items() if v > 0}
+        self.objective = ' + '.join('%g*%s' % (v, k) for k, v in weights.items() if k != 'lpips' or lpips_fn is not None)
+        if 'lpips' in weights and lpips_fn is None:
+            # the reference objective is 1.0*LPIPS + 0.2*MSE (default.yaml:278-281); the VGG trunk is a remote fetch
+            warnings.warn('cfg.train.lossweights.lpips = %g but no lpips_fn was supplied: training on %s only '
+                          '(set lossweights.lpips = 0 to silence this)' % (weights['lpips'], self.objective))
         self.iter = 1
+        self.start_iter = 1
 
-    def train_step(self, batch):
-        """One optimizer step on one frame of this rank (trainer.py:200-231)."""
+    # ------------------------------------------------------------------------------------------ one iteration
+    def backward_step(self, batch):
+        """Forward, loss, backward and the gradient averaging of one iteration (trainer.py:200-218): leaves the
+        (rank-averaged) gradients in ``.grad``."""
         self.network.train()
         self.optimizer.zero_grad(set_to_none=True)
         out = self.network(**batch, iter_val=float(self.iter))
@@ -98,16 +163,107 @@ class Trainer:
         else:                                # flat rays with per-ray targets
             loss, parts = image_loss(out['rgb'][None, None], batch['target_rgbs'][None, None], None)
         loss.backward()
-        hdist.allreduce_gradients(self.network.named_parameters(), self.world_size)
+        self.grad_sync.reduce()
+        return loss.detach(), {k: v.detach() for k, v in parts.items()}
+
+    def optimizer_step(self):
+        """Adam update, learning-rate decay, iteration counter (trainer.py:219, 253-255)."""
         self.optimizer.step()
         update_lr(self.optimizer, self.iter)
         self.iter += 1
-        return loss.detach(), {k: v.detach() for k, v in parts.items()}
 
+    def train_step(self, batch):
+        """One optimizer step on one frame of this rank."""
+        res = self.backward_step(batch)
+        self.optimizer_step()
+        return res
+
+    # ------------------------------------------------------------------------------------------ the loop
+    def train(self, batches, maxiter=None, progress_fn=None, log_fn=print, rank=0):
+        """trainer.py:186-255 over an iterable of per-frame batches (already on the device).  ``progress_fn(trainer)``
+        renders the progress frames; checkpoints are written by rank 0 only."""
+        maxiter = int(cfg.train.maxiter if maxiter is None else maxiter)
+        old = cfg.perturb
+        cfg.perturb = cfg.train.perturb                                   # trainer.py:181
+        try:
+            for batch in batches:
+                if self.iter > maxiter:
+                    break
+                it = self.iter
+                loss, parts = self.train_step(batch)
+                if it % cfg.train.log_interval == 0 and log_fn is not None:
+                    log_fn('Iter %d  Loss: %.4f [%s]' % (it, float(loss), ' '.join('%s: %.4f' % (k, float(v))
+                                                                                   for k, v in parts.items())))
+                dump = cfg.get('progress', {}).get('dump_interval', 5000)
+                if progress_fn is not None and (it == self.start_iter or it in PROGRESS_ITERS or it % dump == 0):
+                    self.iter = it                                        # progress renders with the iteration just run
+                    was = cfg.perturb
+                    cfg.perturb = 0.                                      # trainer.py:263-269
+                    self.network.eval()
+                    try:
+                        progress_fn(self)
+                    finally:
+                        self.network.train()
+                        cfg.perturb = was
+                        self.iter = it + 1
+                if rank == 0 and self.logdir is not None:
+                    self.iter = it                                        # checkpoints carry the iteration just run
+                    try:
+                        if it % cfg.train.save_checkpt_interval == 0 or it == self.start_iter:
+                            self.save_ckpt('latest')
+                        if cfg.get('save_all', False) and it % cfg.train.save_model_interval == 0:
+                            self.save_ckpt('iter_%d' % it)
+                    finally:
+                        self.iter = it + 1
+        finally:
+            cfg.perturb = old
+            self.grad_sync.finish()
+
+    # ------------------------------------------------------------------------------------------ checkpoints
     def state(self):
         return {'iter': self.iter, 'network': self.network.state_dict(), 'optimizer': self.optimizer.state_dict()}
 
     def load_state(self, ckpt):
-        self.iter = ckpt['iter'] + 1
-        self.network.load_state_dict(ckpt['network'], strict=False)
+        """trainer.py:366-377.  Like the reference, the network is loaded non-strictly, but what did not match is
+        reported instead of silently dropped."""
+        self.iter = int(ckpt['iter']) + 1
+        self.start_iter = self.iter
+        res = self.network.load_state_dict(ckpt['network'], strict=False)
+        if res.missing_keys or res.unexpected_keys:
+            warnings.warn('checkpoint does not match the network: missing %s, unexpected %s'
+                          % (sorted(res.missing_keys), sorted(res.unexpected_keys)))
         self.optimizer.load_state_dict(ckpt['optimizer'])
+        return res
+
+    def ckpt_path(self, name):
+        return name if os.path.isfile(name) else os.path.join(self.logdir, '%s.tar' % name)
+
+    def save_ckpt(self, name):
+        os.makedirs(self.logdir, exist_ok=True)
+        path = os.path.join(self.logdir, '%s.tar' % name)
+        torch.save(self.state(), path)
+        return path
+
+    def load_ckpt(self, name, map_location=None):
+        ckpt = load_checkpoint(self.ckpt_path(name), map_location=map_location)
+        return self.load_state(ckpt)
+
+
+def load_checkpoint(path, map_location=None):
+    """Read a ``.tar`` checkpoint of the reference's layout ({'iter', 'network', 'optimizer'}, trainer.py:356-364)
+    without executing anything from the file (``weights_only=True``)."""
+    ckpt = torch.load(path, map_location=map_location or 'cpu', weights_only=True)
+    if not isinstance(ckpt, dict) or 'network' not in ckpt:
+        raise ValueError('%s is not a HumanNeRF checkpoint (keys: %s)' % (path, list(ckpt)[:8] if isinstance(ckpt, dict) else type(ckpt)))
+    return ckpt
+
+
+def load_network(network, path, map_location=None):
+    """run.py:18-34: load ``ckpt['network']`` into ``network`` (non-strict like the reference), reporting every
+    key that did not match."""
+    ckpt = load_checkpoint(path, map_location=map_location)
+    res = network.load_state_dict(ckpt['network'], strict=False)
+    if res.missing_keys or res.unexpected_keys:
+        warnings.warn('checkpoint does not match the network: missing %s, unexpected %s'
+                      % (sorted(res.missing_keys), sorted(res.unexpected_keys)))
+    return res

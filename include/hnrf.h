@@ -163,7 +163,7 @@ int hnrf_render_rays_term_fwd(const float* rays_o, const float* rays_d,
 
 /* =============================== training (backward) ===============================
  * The reference trains through torch.autograd over the ops above (trainer.py:206-220).
- * Here: the forward runs the *_fwd_train variants (HNRF_MLP_F32 only) which also save the
+ * Here: the forward runs the *_fwd_train variants (either arithmetic mode) which also save the
  * positional encodings, the post-ReLU activation matrices and their sign masks; the dX chain of
  * each MLP is one register-resident kernel (hnrf_*_bwd), the weight gradients come from
  * hnrf_mlp_dw, and the stages around the MLPs have the kernels below. */

@@ -59,7 +59,7 @@ def main():
     torch.set_num_threads(8)
     cfg, create_network = import_reference()
     from humannerf_amd import scene
-    from oracle.seeded import seeded_state
+    from humannerf_amd.seeded import seeded_state, with_density
 
     # ---- cross-check the scene helpers against the reference's numpy helpers
     from core.utils import body_util as rb, camera_util as rc
@@ -119,19 +119,39 @@ def main():
         d['head_id'] = torch.tensor(-1)
         return d
 
-    def run_case(name, fr, iter_val, S, perturb=0.0, ignore_nr=False, t_rand=None, keep_rays=24):
+    base_state = state
+
+    def run_case(name, iter_val, S, perturb=0.0, ignore_nr=False, with_t_rand=False, keep_rays=64, frame=None,
+                 density=None, pose_kick_in=None):
+        """One fixture.  ``frame``: overrides of the golden frame's synthetic_frame arguments; ``density``:
+        (bias_delta, gain) for seeded.with_density; ``pose_kick_in``: cfg.pose_decoder.kick_in_iter for this case
+        (the wild configs set it to 20000)."""
+        fa = dict(FRAME, **(frame or {}))
+        fr = scene.synthetic_frame(**fa)
+        st = base_state if density is None else with_density(base_state, *density)
+        net.load_state_dict({k: torch.from_numpy(v) for k, v in st.items()}, strict=True)
         cfg.N_samples = S
         cfg.perturb = perturb
         cfg.ignore_non_rigid_motions = ignore_nr
+        had = cfg.pose_decoder.get('kick_in_iter', None)
+        if pose_kick_in is not None:
+            cfg.pose_decoder.kick_in_iter = pose_kick_in
         captured.clear()
         real_rand = torch.rand
-        if t_rand is not None:
+        t_rand = None
+        if with_t_rand:
+            t_rand = np.random.RandomState(7).rand(fr['rays'].shape[1], S).astype(np.float32)
             torch.rand = lambda *a, **k: torch.from_numpy(t_rand)
         try:
             with torch.no_grad():
                 out = net(**frame_tensors(fr), iter_val=iter_val)
         finally:
             torch.rand = real_rand
+            if pose_kick_in is not None:
+                if had is None:
+                    cfg.pose_decoder.pop('kick_in_iter')
+                else:
+                    cfg.pose_decoder.kick_in_iter = had
         save = {}
         per_sample = ('weights_on_rays', 'xyz_on_rays', 'rgb_on_rays', 'backward_motion_weights', 'offsets')
         for k, v in out.items():
@@ -143,26 +163,41 @@ def main():
             save['t_rand'] = t_rand
         save['_vol_slice'] = net.motion_weights_vol.detach().numpy()[:, 12:20:3, 8:24:5, 8:24:5]
         meta = dict(iter_val=float(iter_val), N_samples=S, perturb=perturb, ignore_non_rigid_motions=ignore_nr,
-                    n_rays=int(out['rgb'].shape[0]), keep_rays=keep_rays)
+                    n_rays=int(out['rgb'].shape[0]), keep_rays=keep_rays, frame=fa,
+                    density=list(density) if density is not None else None, pose_decoder_kick_in_iter=pose_kick_in,
+                    mean_alpha=float(save['alpha'].mean()), max_alpha=float(save['alpha'].max()))
         np.savez_compressed(os.path.join(GOLD, name + '.npz'), **save)
-        st = {k: (float(np.abs(v).mean()), float(np.abs(v).max())) for k, v in save.items() if k in
-              ('rgb', 'alpha', 'depth', 'offsets')}
-        print(name, meta, st)
+        stt = {k: (float(np.abs(v).mean()), float(np.abs(v).max())) for k, v in save.items() if k in
+               ('rgb', 'alpha', 'depth', 'offsets')}
+        print(name, {k: v for k, v in meta.items() if k != 'frame'}, stt)
         return meta
 
     os.makedirs(GOLD, exist_ok=True)
-    fr = scene.synthetic_frame(H=512, W=512, focal_at_512=1250.0, ray_stride=41)
-    print('rays in golden frame:', fr['rays'].shape)
-    metas = {'frame': dict(H=512, W=512, focal_at_512=1250.0, ray_stride=41, pose_seed=0, seed=0)}
-    metas['eval_s128'] = run_case('eval_s128', fr, 1e7, 128)
-    metas['eval_s64'] = run_case('eval_s64', fr, 1e7, 64)
-    metas['tpose_s128'] = run_case('tpose_s128', fr, 1e7, 128, ignore_nr=True)
-    metas['iter0_s128'] = run_case('iter0_s128', fr, 0.0, 128)
-    metas['iter5000_s128'] = run_case('iter5000_s128', fr, 5000.0, 128)
-    metas['iter30000_s128'] = run_case('iter30000_s128', fr, 30000.0, 128)
-    R = fr['rays'].shape[1]
-    t_rand = np.random.RandomState(7).rand(R, 128).astype(np.float32)
-    metas['perturb_s128'] = run_case('perturb_s128', fr, 1e7, 128, perturb=1.0, t_rand=t_rand)
+    for old in os.listdir(GOLD):
+        if old.endswith('.npz') and not old.startswith('patches') and not old.startswith(('image_', 'dataset_')):
+            os.remove(os.path.join(GOLD, old))
+    # ~260 rays of the 512x512 T-pose framing, per-sample tensors kept for the first 64
+    FRAME = dict(H=512, W=512, focal_at_512=1250.0, ray_stride=30, pose_seed=0, bgcolor=(0.0, 0.0, 0.0))
+    print('rays in golden frame:', scene.synthetic_frame(**FRAME)['rays'].shape)
+    metas = {'frame': dict(FRAME, seed=0)}
+    metas['eval_s128'] = run_case('eval_s128', 1e7, 128)
+    metas['eval_s64'] = run_case('eval_s64', 1e7, 64)
+    metas['eval_s256'] = run_case('eval_s256', 1e7, 256)                      # BASELINE config 5 sampling
+    metas['tpose_s128'] = run_case('tpose_s128', 1e7, 128, ignore_nr=True)
+    metas['iter0_s128'] = run_case('iter0_s128', 0.0, 128)                    # below both kick-ins: cond and PE zeroed
+    metas['iter12000_s128'] = run_case('iter12000_s128', 12000.0, 128)        # first Hann band partly open
+    metas['iter30000_s128'] = run_case('iter30000_s128', 30000.0, 128)        # bands 0-2 open, band 3 closed
+    metas['perturb_s128'] = run_case('perturb_s128', 1e7, 128, perturb=1.0, with_t_rand=True)
+    # wild configs: white background (network.py:379 bg blend) and the pose decoder held back (network.py:667)
+    metas['whitebg_s128'] = run_case('whitebg_s128', 1e7, 128, frame=dict(bgcolor=(255.0, 255.0, 255.0)))
+    metas['posehold_s128'] = run_case('posehold_s128', 12000.0, 128, pose_kick_in=20000)
+    # dense medium, camera zoomed on the torso: most rays saturate (transmittance scan over many opaque samples)
+    metas['dense_s128'] = run_case('dense_s128', 1e7, 128, frame=dict(focal_at_512=3200.0, ray_stride=31),
+                                   density=(45.0, 4.0))
+    metas['dense_white_s64'] = run_case('dense_white_s64', 30000.0, 64, perturb=1.0, with_t_rand=True,
+                                        frame=dict(focal_at_512=3200.0, ray_stride=31, bgcolor=(255.0, 255.0, 255.0)),
+                                        density=(45.0, 4.0))
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in base_state.items()}, strict=True)
 
     # ---- gradients of a scalar loss through the reference (training path, trainer.py:206-220)
     cfg.N_samples, cfg.perturb, cfg.ignore_non_rigid_motions = 64, 0.0, False

@@ -20,15 +20,38 @@ def golden_dir():
 @pytest.fixture(scope='session')
 def seeded_params():
     """The seeded 64.4 M-parameter state the golden fixtures were made with."""
-    from oracle.seeded import default_shapes, seeded_state
+    from humannerf_amd.seeded import default_shapes, seeded_state
     return seeded_state(default_shapes(), seed=0)
 
 
 @pytest.fixture(scope='session')
-def golden_frame():
+def golden_meta():
     import json
-    from humannerf_amd import scene
     with open(os.path.join(ROOT, 'tests', 'golden', 'meta.json')) as f:
-        m = json.load(f)['frame']
-    return scene.synthetic_frame(H=m['H'], W=m['W'], focal_at_512=m['focal_at_512'],
-                                 ray_stride=m['ray_stride'], pose_seed=m['pose_seed'])
+        return json.load(f)
+
+
+@pytest.fixture(scope='session')
+def golden_frame(golden_meta):
+    """The default golden frame (cases may override parts of it: golden_case)."""
+    from humannerf_amd import scene
+    m = {k: v for k, v in golden_meta['frame'].items() if k != 'seed'}
+    return scene.synthetic_frame(**m)
+
+
+@pytest.fixture(scope='session')
+def golden_case(golden_meta, seeded_params):
+    """case name -> (meta, npz, frame, state): the inputs oracle/make_golden.py fed the reference for that case."""
+    import numpy as np
+    from humannerf_amd import scene
+    from humannerf_amd.seeded import with_density
+    frames = {}
+
+    def get(case):
+        m = golden_meta[case]
+        key = repr(sorted(m['frame'].items()))
+        if key not in frames:
+            frames[key] = scene.synthetic_frame(**m['frame'])
+        state = seeded_params if m['density'] is None else with_density(seeded_params, *m['density'])
+        return m, np.load(os.path.join(ROOT, 'tests', 'golden', case + '.npz')), frames[key], state
+    return get

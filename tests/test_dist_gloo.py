@@ -1,7 +1,14 @@
-"""world_size-2 gloo tests of the multi-GPU layer (runs on CPU)."""
+"""world_size-2 gloo tests of the multi-GPU layer (runs on CPU).
+
+The renderer itself needs the GPU (tests/test_gpu_dist.py does the same with the real Network on the box); here the
+GradientSync logic is exercised on the real weight-volume decoder (a 16^3 instance) with a stand-in for the
+per-sample path: any differentiable function of (volume, small parameters) will do, because what is being
+checked is that averaging the volume gradient in front of the decoder backward + one flat bucket for the rest
+gives exactly the mean of the per-rank gradients."""
 import os
 import socket
 
+import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -15,43 +22,124 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, q):
+class _Toy(torch.nn.Module):
+    """mweight_vol_decoder (real, 16^3) + two small parameter sets named like the network's."""
+
+    def __init__(self):
+        super().__init__()
+        from humannerf_amd.network import MotionWeightVolumeDecoder
+        torch.manual_seed(1)
+        self.mweight_vol_decoder = MotionWeightVolumeDecoder(embedding_size=32, volume_size=16, total_bones=24)
+        self.cnl_mlp = torch.nn.Linear(6, 4)
+        self.pose_decoder = torch.nn.Linear(5, 3)          # gets NO gradient in `loss` when use_pose is False
+        self.grad_sync = None
+
+    def loss(self, priors, seed, use_pose=True):
+        g = torch.Generator().manual_seed(seed)
+        vol = self.mweight_vol_decoder(motion_weights_priors=priors[None])[0]
+        if self.grad_sync is not None:
+            vol = self.grad_sync.volume_hook(vol, priors)
+        a = torch.randn(vol.shape, generator=g)
+        x = torch.randn(9, 6, generator=g)
+        out = (vol * a).sum() * 0.01 + self.cnl_mlp(x).pow(2).sum() * (vol[:24] * a[:24]).mean()
+        if use_pose:
+            out = out + self.pose_decoder(torch.randn(2, 5, generator=g)).sum()
+        return out
+
+
+def _priors(seed=0):
+    g = torch.Generator().manual_seed(100 + seed)
+    p = torch.rand(25, 16, 16, 16, generator=g) + 0.05
+    return p / p.sum(0, keepdim=True)
+
+
+def _worker(rank, world, port, q, mode, use_pose, priors_differ):
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
     dist.init_process_group('gloo', rank=rank, world_size=world)
+    torch.set_num_threads(2)
     from humannerf_amd import dist as hd
-    # frame sharding + ordered gather: stand-in renderer = deterministic function of the frame index
-    n_frames = 7
-    mine = hd.frame_shard(n_frames, rank, world)
-    local = {i: torch.full((4, 3), float(i)) * (i + 1) for i in mine}
-    frames = hd.gather_frames(local, n_frames, rank, world)
-    # gradient all-reduce == mean of the per-rank grads, both buckets
-    torch.manual_seed(0)
-    params = [('mweight_vol_decoder.w', torch.nn.Parameter(torch.zeros(5, 3))),
-              ('cnl_mlp.module.w', torch.nn.Parameter(torch.zeros(7))),
-              ('pose_decoder.b', torch.nn.Parameter(torch.zeros(2)))]
-    for k, (_, p) in enumerate(params):
-        p.grad = torch.full_like(p, float(rank + 1) * (k + 1))
-    hd.allreduce_gradients(params, world)
-    if rank == 0:
-        q.put(([f.tolist() for f in frames], [p.grad.tolist() for _, p in params]))
-    dist.barrier()
-    dist.destroy_process_group()
+    try:
+        # frame sharding + ordered gather: stand-in renderer = deterministic function of the frame index
+        n_frames = 7
+        mine = hd.frame_shard(n_frames, rank, world)
+        local = {i: torch.full((4, 3), float(i)) * (i + 1) for i in mine}
+        frames = hd.gather_frames(local, n_frames, rank, world)
+
+        net = _Toy()
+        sync = hd.GradientSync(net, world, mode=mode)
+        net.grad_sync = sync
+        err = None
+        try:
+            net.loss(_priors(rank if priors_differ else 0), seed=10 + rank, use_pose=use_pose).backward()
+            sync.reduce()
+            sync.finish()
+        except RuntimeError as e:
+            err = str(e)
+        grads = {n: (None if p.grad is None else p.grad.clone()) for n, p in net.named_parameters()}
+        nbytes = sync.take_bytes()
+        if rank == 0:
+            q.put(([f.tolist() for f in frames] if frames is not None else None, grads, nbytes, err))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
 
 
-def test_frame_shard_and_grad_allreduce_world2():
+def _run(mode, use_pose=True, priors_differ=False):
     world, port = 2, _free_port()
     ctx = mp.get_context('spawn')
     q = ctx.SimpleQueue()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, mode, use_pose, priors_differ)) for r in range(world)]
     for p in procs:
         p.start()
-    frames, grads = q.get()
+    res = q.get()
     for p in procs:
-        p.join(60)
+        p.join(120)
         assert p.exitcode == 0
-    assert [f[0][0] for f in frames] == [float(i) * (i + 1) for i in range(7)]     # serial order
-    mean = (1 + 2) / 2.0
-    assert grads[0][0][0] == mean * 1 and grads[1][0] == mean * 2 and grads[2][0] == mean * 3
+    return res
+
+
+def _serial_mean(use_pose=True):
+    torch.set_num_threads(2)
+    acc = None
+    for rank in range(2):
+        net = _Toy()
+        net.loss(_priors(0), seed=10 + rank, use_pose=use_pose).backward()
+        g = {n: p.grad for n, p in net.named_parameters()}
+        acc = g if acc is None else {n: (None if g[n] is None else (acc[n] + g[n]) / 2) for n in g}
+    return acc
+
+
+@pytest.mark.parametrize('mode', ['volume', 'full'])
+def test_gradient_sync_equals_mean_of_rank_gradients(mode):
+    frames, grads, nbytes, err = _run(mode)
+    assert err is None, err
+    assert [f[0][0] for f in frames] == [float(i) * (i + 1) for i in range(7)]     # serial frame order
+    want = _serial_mean()
+    assert set(grads) == set(want)
+    for n in want:
+        scale = float(want[n].abs().max()) + 1e-12
+        assert float((grads[n] - want[n]).abs().max()) <= 2e-6 * scale, n
+    n_dec = sum(p.numel() for n, p in _Toy().named_parameters() if 'mweight_vol_decoder' in n)
+    if mode == 'volume':
+        # the decoder's own gradients never travel: volume (25*16^3) + small bucket only
+        assert nbytes < 4 * (25 * 16 ** 3 + 200) and nbytes < 4 * n_dec / 10
+    else:
+        assert nbytes > 4 * n_dec
+
+
+def test_parameters_without_gradient_stay_none():
+    """a parameter no rank produced a gradient for must not be stepped (grad stays None)."""
+    _, grads, _, err = _run('volume', use_pose=False)
+    assert err is None, err
+    assert grads['pose_decoder.weight'] is None and grads['pose_decoder.bias'] is None
+    want = _serial_mean(use_pose=False)
+    assert float((grads['cnl_mlp.weight'] - want['cnl_mlp.weight']).abs().max()) <= 1e-6
+
+
+def test_volume_mode_detects_rank_dependent_priors():
+    """The volume trick needs replicated decoder activations; different priors per rank must raise."""
+    _, _, _, err = _run('volume', priors_differ=True)
+    assert err is not None and 'priors differ' in err
 
 
 def test_frame_shard_covers_everything():

@@ -1,11 +1,12 @@
 """Parity of the HIP path (through the C ABI) against the CPU oracle and the
 reference-generated golden fixtures.  Needs an MI355X: ``pytest -m gpu``.
 
-fp32 tolerance of the build (mode 'f32', v_mfma_f32_32x32x2_f32), stated once:
-  per-ray  rgb, alpha            |err| <= 5e-5      (reference's own fp32 noise: 1.0e-5 / 1.5e-5)
-           depth                 |err| <= 4e-4      (values up to ~6; reference noise 9e-5)
-  PSNR(rgb) vs reference         >= 80 dB
-  per-sample positions           |err| <= 1e-4      (reference noise 6e-5 where sum w ~ 1e-4)
+fp32 tolerance of the build (both MLP arithmetics), stated once -- SURVEY.md section 8(c):
+  per-ray  rgb, alpha            |err| <= 2e-5      (reference's own fp32 noise: 1.0e-5 / 1.5e-5)
+           depth                 |err| <= 1e-4 far  (far ~ 5..7; reference noise 9e-5)
+  PSNR(rgb) vs reference         >= 90 dB
+  per-sample positions           |err| <= 1e-5 where sum w > 1e-3, <= 1e-4 inside the 1e-4 clamp of the
+                                 skinning-weight sum (reference noise 6e-5 there)
 Per-sample colours sit behind a 2^9 positional-encoding band and are compared
 loosely (see tests/test_oracle_golden.py).
 """
@@ -18,7 +19,7 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
-TOL_RGB, TOL_ALPHA, TOL_DEPTH, TOL_XYZ = 5e-5, 5e-5, 4e-4, 1e-4
+TOL_RGB, TOL_ALPHA, TOL_DEPTH_PER_FAR, TOL_XYZ, TOL_XYZ_SOLID = 2e-5, 2e-5, 1e-4, 1e-4, 1e-5
 
 
 def dev():
@@ -48,44 +49,66 @@ def frame_to_gpu(fr):
 
 
 # ------------------------------------------------------------------ whole path vs the reference
-CASES = ['eval_s128', 'eval_s64', 'tpose_s128', 'iter0_s128', 'iter5000_s128', 'iter30000_s128', 'perturb_s128']
+CASES = ['eval_s128', 'eval_s64', 'eval_s256', 'tpose_s128', 'iter0_s128', 'iter12000_s128', 'iter30000_s128', 'perturb_s128',
+         'whitebg_s128', 'posehold_s128', 'dense_s128', 'dense_white_s64']
+HEAD = ('cnl_mlp.module.output_linear.0.weight', 'cnl_mlp.module.output_linear.0.bias')
 
 
 @pytest.mark.parametrize('mode', ['f32', 'f16x3'])
 @pytest.mark.parametrize('case', CASES)
-def test_network_matches_reference_golden(case, mode, gpu_net, golden_frame, golden_dir):
+def test_network_matches_reference_golden(case, mode, gpu_net, golden_case, seeded_params):
+    """Network.forward on the GPU vs the outputs of the REFERENCE on identical rays / weights: 12 cases (sampling
+    density 64 / 128 / 256, T-pose branch, iterations below / inside / above the Hann window, stratified sampling,
+    white background, pose decoder held back, dense medium with saturated rays) x both MLP arithmetics."""
     from humannerf_amd.config import cfg
+    m, g, frame, state = golden_case(case)
     cfg.amd.mlp_mode = mode
-    with open(os.path.join(golden_dir, 'meta.json')) as f:
-        m = json.load(f)[case]
-    g = np.load(os.path.join(golden_dir, case + '.npz'))
     cfg.N_samples, cfg.perturb = m['N_samples'], m['perturb']
     cfg.ignore_non_rigid_motions = m['ignore_non_rigid_motions']
+    if m['pose_decoder_kick_in_iter'] is not None:
+        cfg.pose_decoder.kick_in_iter = m['pose_decoder_kick_in_iter']
     kw = {}
     if 't_rand' in g.files:
         kw['t_rand'] = torch.from_numpy(g['t_rand']).to(dev())
+    sd = gpu_net.state_dict()
     try:
         with torch.no_grad():
-            out = gpu_net(**frame_to_gpu(golden_frame), iter_val=m['iter_val'], **kw)
+            for k in HEAD:                                  # the dense cases differ in the sigma row of the head
+                sd[k].copy_(torch.from_numpy(state[k]))
+            out = gpu_net(**frame_to_gpu(frame), iter_val=m['iter_val'], **kw)
     finally:
+        with torch.no_grad():
+            for k in HEAD:
+                sd[k].copy_(torch.from_numpy(seeded_params[k]))
         cfg.N_samples, cfg.perturb, cfg.ignore_non_rigid_motions = 128, 1.0, False
         cfg.amd.mlp_mode = 'f16x3'
+        cfg.pose_decoder.pop('kick_in_iter', None)
     out = {k: v.cpu().numpy() for k, v in out.items()}
-    print(case, mode, 'max err rgb %.2e alpha %.2e depth %.2e' % (np.abs(out['rgb'] - g['rgb']).max(),
-          np.abs(out['alpha'] - g['alpha']).max(), np.abs(out['depth'] - g['depth']).max()))
+    tol_depth = TOL_DEPTH_PER_FAR * frame['far'][:, 0]
+    d_depth = np.abs(out['depth'] - g['depth'])
+    print(case, mode, 'max err rgb %.2e alpha %.2e depth %.2e (tol %.1e)' % (
+        np.abs(out['rgb'] - g['rgb']).max(), np.abs(out['alpha'] - g['alpha']).max(), d_depth.max(), tol_depth.min()))
     assert set(out) == {'rgb', 'alpha', 'depth', 'weights_on_rays', 'xyz_on_rays', 'rgb_on_rays', 'cnl_xyz',
                         'cnl_rgb', 'cnl_weight', 'backward_motion_weights', 'offsets'}
     n = m['keep_rays']
     assert out['rgb'].shape == (m['n_rays'], 3) and out['weights_on_rays'].shape == (m['n_rays'], m['N_samples'])
-    assert np.abs(out['rgb'] - g['rgb']).max() <= TOL_RGB
-    assert np.abs(out['alpha'] - g['alpha']).max() <= TOL_ALPHA
-    assert np.abs(out['depth'] - g['depth']).max() <= TOL_DEPTH
-    assert psnr(out['rgb'], g['rgb']) >= 80.0
-    assert np.abs(out['cnl_weight'] - g['cnl_weight']).max() <= TOL_ALPHA
-    assert np.abs(out['weights_on_rays'][:n] - g['weights_on_rays']).max() <= TOL_ALPHA
-    assert np.abs(out['xyz_on_rays'][:n] - g['xyz_on_rays']).max() <= TOL_XYZ
-    assert np.abs(out['offsets'][:n] - g['offsets']).max() <= TOL_XYZ
+    # dense-medium cases (sigma up to ~400, saturated rays): the reference's own fp32 result is 1.8e-5 (rgb) / 2.4e-5
+    # (alpha) away from an fp64 evaluation of the same formulas, so 2e-5 cannot be asked of anybody there: 4e-5
+    slack = 2.0 if m['density'] is not None else 1.0
+    assert np.abs(out['rgb'] - g['rgb']).max() <= slack * TOL_RGB
+    assert np.abs(out['alpha'] - g['alpha']).max() <= slack * TOL_ALPHA
+    assert (d_depth <= tol_depth).all()
+    assert psnr(out['rgb'], g['rgb']) >= 90.0
+    assert np.abs(out['cnl_weight'] - g['cnl_weight']).max() <= slack * TOL_ALPHA
+    assert np.abs(out['weights_on_rays'][:n] - g['weights_on_rays']).max() <= slack * TOL_ALPHA
+    # positions: tight where the skinning-weight sum is away from its 1e-4 clamp, TOL_XYZ inside the clamp region
+    # (ill-conditioned division, see tests/test_oracle_golden.py)
+    solid = g['_mask'] > 1e-3
+    for k in ('xyz_on_rays', 'offsets'):
+        err = np.abs(out[k][:n] - g[k]).max(axis=-1)
+        assert err[solid].max() <= TOL_XYZ_SOLID and err.max() <= TOL_XYZ, (k, err[solid].max(), err.max())
     assert np.abs(out['backward_motion_weights'][:n] - g['backward_motion_weights']).max() <= 1e-5
+    assert np.abs(out['rgb_on_rays'][:n] - g['rgb_on_rays'])[solid].max() <= 2e-3
     assert np.abs(out['rgb_on_rays'][:n] - g['rgb_on_rays']).max() <= 2e-2
     sel = g['cnl_weight'] > 1e-4
     same = np.abs(out['cnl_xyz'][sel] - g['cnl_xyz'][sel]).max(axis=-1) < 1e-3
@@ -154,7 +177,7 @@ def test_sample_warp_kernel_edges():
 
 
 def _mlp_states(rs):
-    from oracle.seeded import default_shapes
+    from humannerf_amd.seeded import default_shapes
     st = {}
     for k, s in default_shapes().items():
         if k.startswith('cnl_mlp') or k.startswith('non_rigid_mlp'):
@@ -189,14 +212,37 @@ def test_canonical_mlp_kernel(P, mode):
     assert e_hip <= 4 * e_cpu + 1e-6, (e_hip, e_cpu)      # as accurate as the CPU fp32 path
 
 
+def _apply_regime(st, regime, rs):
+    """Weight regimes of the non-rigid MLP the kernels must survive in BOTH arithmetics:
+      scaled       Xavier weights, last layer x0.1 (offsets of a few cm: a trained network)
+      fresh_init   the reference's initialisation: last layer U(+-1e-5), zero bias (mlp_offset.py:60-66) -- every
+                   hi = f16(w) of that layer is an f16 SUBNORMAL in the split-f16 kernels
+      tiny_hidden  a hidden layer (block_mlps.4) scaled so that its weights and biases are ~1e-6."""
+    p = 'non_rigid_mlp.module.block_mlps.'
+    if regime == 'scaled':
+        st[p + '12.weight'] *= 0.1
+    elif regime == 'fresh_init':
+        st[p + '12.weight'] = rs.uniform(-1e-5, 1e-5, st[p + '12.weight'].shape).astype(np.float32)
+        st[p + '12.bias'] = np.zeros_like(st[p + '12.bias'])
+    elif regime == 'tiny_hidden':
+        st[p + '4.weight'] *= np.float32(1e-5)
+        st[p + '4.bias'] *= np.float32(1e-5)
+    else:
+        raise ValueError(regime)
+    return st
+
+
 @pytest.mark.parametrize('mode', ['f32', 'f16x3'])
-@pytest.mark.parametrize('P,iter_val', [(1, 1e7), (97, 1e7), (2048, 30000.0), (555, 0.0)])
-def test_nonrigid_mlp_kernel(P, iter_val, mode):
+@pytest.mark.parametrize('P,iter_val,regime', [(1, 1e7, 'scaled'), (97, 1e7, 'scaled'), (2048, 30000.0, 'scaled'),
+                                               (555, 0.0, 'scaled'), (1500, 1e7, 'fresh_init'), (1500, 1.0, 'fresh_init'),
+                                               (1500, 1e7, 'tiny_hidden')])
+def test_nonrigid_mlp_kernel(P, iter_val, regime, mode):
+    """K2 vs an fp64 evaluation.  Error bound relative to the OUTPUT magnitude (the offsets): 1e-5 max|offset|, and the
+    accuracy of a torch fp32 evaluation on the CPU as the yardstick."""
     from humannerf_amd import ops
     from oracle import oracle
     rs = np.random.RandomState(P + 7)
-    st = _mlp_states(rs)
-    st['non_rigid_mlp.module.block_mlps.12.weight'] *= 0.1
+    st = _apply_regime(_mlp_states(rs), regime, rs)
     x = rs.uniform(-1.3, 1.3, (P, 3)).astype(np.float32)
     cond = rs.uniform(-0.5, 0.5, (69,)).astype(np.float32)
     if iter_val < 10000:
@@ -211,8 +257,15 @@ def test_nonrigid_mlp_kernel(P, iter_val, mode):
     st64 = {k: torch.from_numpy(v).double() for k, v in st.items()}
     xyz64, ofs64 = oracle.non_rigid_mlp(st64, oracle.hann_pe(torch.from_numpy(x).double(), hw.double()),
                                         torch.from_numpy(cond).double()[None], torch.from_numpy(x).double())
-    assert np.abs(ofs.cpu().numpy() - ofs64.numpy()).max() <= 2e-6 * max(1.0, float(ofs64.abs().max()) * 10)
-    assert np.abs(xyz.cpu().numpy() - xyz64.numpy()).max() <= 1e-6 + 2e-6 * float(ofs64.abs().max()) * 10
+    _, ofs32 = oracle.non_rigid_mlp({k: torch.from_numpy(v) for k, v in st.items()},
+                                    oracle.hann_pe(torch.from_numpy(x), hw), torch.from_numpy(cond)[None], torch.from_numpy(x))
+    top = float(ofs64.abs().max())
+    e_hip = float(np.abs(ofs.cpu().numpy() - ofs64.numpy()).max()) / top
+    e_cpu = float((ofs32.double() - ofs64).abs().max()) / top
+    print('nonrigid', mode, regime, P, 'max|offset| %.2e rel err hip %.2e cpu-fp32 %.2e' % (top, e_hip, e_cpu))
+    assert e_hip <= 1e-5, (e_hip, e_cpu)
+    assert e_hip <= 8 * e_cpu + 2e-7, (e_hip, e_cpu)          # fp32-class: within a small factor of torch's fp32
+    assert np.abs(xyz.cpu().numpy() - xyz64.numpy()).max() <= 2e-7 * 1.3 + 1e-5 * top
     xyz2, none = ops.nonrigid(T(x), hw.to(dev()), packed, mode, want_offsets=False)
     assert none is None and torch.equal(xyz, xyz2)
 
@@ -357,7 +410,7 @@ def test_render_frames_driver(gpu_net):
 
 def test_ray_chunking_is_invisible(gpu_net, golden_frame):
     """Network._batchify_rays (network.py:330-352): results do not depend on cfg.chunk, also when the
-    last chunk is ragged (144 rays in chunks of 50) and in the 11-output diagnostic path."""
+    last chunk is ragged (256 rays in chunks of 50) and in the 11-output diagnostic path."""
     from humannerf_amd.config import cfg
     cfg.perturb = 0.
     try:

@@ -24,7 +24,7 @@ def grad_frame(meta):
 
 def compare_grads(grads, g, rel_norm=2e-3, cos_min=0.9995):
     """grads: name -> ndarray.  g: the golden npz."""
-    checked = 0
+    checked, worst_norm, worst_cos = 0, (0.0, None), (1.0, None)
     for key in g.files:
         if not key.startswith('norm/'):
             continue
@@ -33,6 +33,8 @@ def compare_grads(grads, g, rel_norm=2e-3, cos_min=0.9995):
         got = grads[name]
         gn = float(np.linalg.norm(got.astype(np.float64)))
         assert abs(gn - ref_norm) <= rel_norm * max(ref_norm, 1e-8), (name, gn, ref_norm)
+        if ref_norm > 0:
+            worst_norm = max(worst_norm, (abs(gn - ref_norm) / ref_norm, name))
         ref = g['grad/' + name] if 'grad/' + name in g.files else None
         a = got.reshape(-1)
         if ref is None and 'head/' + name in g.files:
@@ -41,8 +43,10 @@ def compare_grads(grads, g, rel_norm=2e-3, cos_min=0.9995):
             r = ref.reshape(-1).astype(np.float64)
             cos = float(a.astype(np.float64) @ r / (np.linalg.norm(a) * np.linalg.norm(r) + 1e-300))
             assert cos >= cos_min, (name, cos)
+            worst_cos = min(worst_cos, (cos, name))
         checked += 1
     assert checked == 55
+    return {'worst_rel_norm_err': worst_norm, 'worst_cosine': worst_cos}
 
 
 def test_oracle_autograd_matches_reference(seeded_params, golden_dir):

@@ -13,7 +13,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def test_state_dict_contract():
     """Key names and shapes of the reference checkpoint."""
     from humannerf_amd.network import Network
-    from oracle.seeded import default_shapes
+    from humannerf_amd.seeded import default_shapes
     net = Network()
     sd = {k: tuple(v.shape) for k, v in net.state_dict().items()}
     assert sd == default_shapes()
@@ -175,3 +175,76 @@ def test_patch_sampler_matches_reference(golden_dir):
     assert np.array_equal(info['mask'], g['mask'])
     assert np.array_equal(info['xy_min'], g['xy_min']) and np.array_equal(info['xy_max'], g['xy_max'])
     assert (~g['mask']).any() and div[-1] < 6 * 400          # the fixture really has partly covered windows
+
+
+def test_grouped_adam_is_torch_adam_with_fewer_launches():
+    """train.GroupedAdam: same numbers as torch.optim.Adam over the reference's one-group-per-tensor layout, None
+    gradients skipped (their step counters do not advance), state_dict in torch's standard form."""
+    from humannerf_amd.train import GroupedAdam
+    torch.manual_seed(0)
+    ps = [torch.randn(5, 3), torch.randn(7), torch.randn(2, 2)]
+    a = [p.clone().requires_grad_() for p in ps]
+    b = [p.clone().requires_grad_() for p in ps]
+    ga = GroupedAdam([{'params': [a[0]], 'lr': 1e-2, 'name': 'x'}, {'params': [a[1]], 'name': 'y'},
+                      {'params': [a[2]], 'lr': 1e-2, 'name': 'z'}], lr=1e-3)
+    gb = torch.optim.Adam([{'params': [b[0]], 'lr': 1e-2}, {'params': [b[1]]}, {'params': [b[2]], 'lr': 1e-2}], lr=1e-3)
+    for it in range(6):
+        for x, y in zip(a, b):
+            g = torch.randn_like(x)
+            x.grad, y.grad = g.clone(), g.clone()
+        if it == 2:
+            a[1].grad = b[1].grad = None
+        ga.step()
+        gb.step()
+    for x, y in zip(a, b):
+        assert (x - y).abs().max() <= 1e-7
+    sd = ga.state_dict()
+    assert float(sd['state'][0]['step']) == 6.0 and float(sd['state'][1]['step']) == 5.0
+    assert [g['name'] for g in sd['param_groups']] == ['x', 'y', 'z']
+    fresh = GroupedAdam([{'params': [p.clone().requires_grad_()], 'name': n} for p, n in zip(ps, 'xyz')], lr=1e-3)
+    fresh.load_state_dict(sd)
+    assert torch.equal(fresh.state_dict()['state'][2]['exp_avg'], sd['state'][2]['exp_avg'])
+
+
+def test_unbuilt_config_branches_raise():
+    """every switch of the reference constructors that selects a branch outside the hot path must
+    raise instead of being ignored (a checkpoint trained with it would otherwise load non-strictly and render wrong)."""
+    from humannerf_amd.config import get_cfg_defaults
+    from humannerf_amd.network import check_config_is_built
+    check_config_is_built(get_cfg_defaults())
+    for path, val in [('canonical_mlp.mlp_depth_plus', 2), ('non_rigid_motion_mlp.mlp_depth_plus', 1),
+                      ('canonical_mlp.last_linear_scale', 2), ('non_rigid_motion_mlp.i_embed', -1),
+                      ('canonical_mlp.time_input', True), ('non_rigid_motion_mlp.time_input', True),
+                      ('rgb_history.last_num', 3), ('non_rigid_motion_mlp.multihead.enable', True),
+                      ('canonical_mlp.multihead.enable', True), ('canonical_mlp.view_dir', True),
+                      ('non_rigid_motion_model', 'transformer_encoder'), ('posevec.type', 'matrix'),
+                      ('condition_code.type', 'local'),
+                      ('embedder.module', 'core.nets.human_nerf.embedders.vocab_embedder'),
+                      ('non_rigid_embedder.module', 'core.nets.human_nerf.embedders.fourier')]:
+        c = get_cfg_defaults()
+        node = c
+        parts = path.split('.')
+        for p_ in parts[:-1]:
+            if p_ not in node:
+                node[p_] = {}
+            node = node[p_]
+        node[parts[-1]] = val
+        with pytest.raises(NotImplementedError, match=parts[-1]):
+            check_config_is_built(c)
+    # the reference's default module paths pass (compared by last component)
+    c = get_cfg_defaults()
+    c.embedder = {'module': 'core.nets.human_nerf.embedders.fourier'}
+    c.non_rigid_embedder = {'module': 'core.nets.human_nerf.embedders.hannw_fourier'}
+    check_config_is_built(c)
+
+
+def test_trainer_states_mse_only_objective():
+    """lossweights.lpips > 0 without an lpips_fn must not pass silently."""
+    import warnings
+    from humannerf_amd.network import Network
+    from humannerf_amd.train import Trainer
+    net = Network()
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter('always')
+        tr = Trainer(net)
+    assert any('lpips' in str(x.message) for x in w) and tr.objective == '0.2*mse'

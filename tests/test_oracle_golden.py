@@ -15,25 +15,29 @@ import torch
 
 from oracle import oracle
 
-CASES = ['eval_s128', 'eval_s64', 'tpose_s128', 'iter0_s128', 'iter5000_s128', 'iter30000_s128', 'perturb_s128']
+CASES = ['eval_s128', 'eval_s64', 'eval_s256', 'tpose_s128', 'iter0_s128', 'iter12000_s128', 'iter30000_s128', 'perturb_s128',
+         'whitebg_s128', 'posehold_s128', 'dense_s128', 'dense_white_s64']
 PER_RAY = {'rgb': 1e-5, 'alpha': 1e-5, 'depth': 5e-5, 'cnl_weight': 1e-5}
-PER_SAMPLE = {'weights_on_rays': 1e-5, 'xyz_on_rays': 2e-5, 'rgb_on_rays': 1e-2,
-              'backward_motion_weights': 1e-5, 'offsets': 2e-5,
-              '_x_skel': 2e-5, '_mask': 1e-5, '_z_vals': 1e-6}
+PER_SAMPLE = {'weights_on_rays': 1e-5, 'rgb_on_rays': 1e-2, 'backward_motion_weights': 1e-5, '_mask': 1e-5, '_z_vals': 1e-6}
+# positions: x_skel = sum_i w_i pos_i / max(sum w, 1e-4) (network.py:425-429) is ill-conditioned exactly where the
+# clamp is active -- there fp32 summation order moves it by up to ~6e-5 (and alpha is multiplied by sum w < 1e-4, so
+# it cannot matter); everywhere else the restatement agrees with the reference to a few ulp
+POSITIONS = {'xyz_on_rays': (5e-6, 1e-4), 'offsets': (5e-6, 1e-4), '_x_skel': (5e-6, 1e-4)}
 
 
 @pytest.fixture(scope='module')
-def oracle_outputs(seeded_params, golden_frame, golden_dir):
+def oracle_outputs(golden_case):
     cache = {}
 
     def get(case):
         if case not in cache:
-            with open(os.path.join(golden_dir, 'meta.json')) as f:
-                m = json.load(f)[case]
-            g = np.load(os.path.join(golden_dir, case + '.npz'))
+            m, g, frame, state = golden_case(case)
             t_rand = g['t_rand'] if 't_rand' in g.files else None
-            out = oracle.render(seeded_params, golden_frame, iter_val=m['iter_val'], t_rand=t_rand,
-                                N_samples=m['N_samples'], ignore_non_rigid_motions=m['ignore_non_rigid_motions'])
+            kw = {}
+            if m['pose_decoder_kick_in_iter'] is not None:
+                kw['pose_decoder_kick_in_iter'] = m['pose_decoder_kick_in_iter']
+            out = oracle.render(state, frame, iter_val=m['iter_val'], t_rand=t_rand, N_samples=m['N_samples'],
+                                ignore_non_rigid_motions=m['ignore_non_rigid_motions'], **kw)
             cache[case] = ({k: v.numpy() for k, v in out.items()}, g, m)
         return cache[case]
     return get
@@ -50,9 +54,14 @@ def test_oracle_matches_reference(case, oracle_outputs):
     for k, tol in PER_SAMPLE.items():
         err = np.abs(out[k][:n] - g[k]).max()
         assert err <= tol, (k, err)
+    solid = g['_mask'] > 1e-3
+    for k, (tight, loose) in POSITIONS.items():
+        err = np.abs(out[k][:n] - g[k]).max(axis=-1)
+        assert err[solid].max() <= tight and err.max() <= loose, (k, err[solid].max(), err.max())
     # raw sigma feeds exp(): compare where it matters (relu'd and masked)
-    err = np.abs(out['_raw'][:n] - g['_raw']).max()
-    assert err <= 2e-3 * max(1.0, np.abs(g['_raw']).max()), err
+    err = np.abs(out['_raw'][:n] - g['_raw']).max(axis=-1)
+    top = max(1.0, np.abs(g['_raw']).max())
+    assert err[solid].max() <= 5e-4 * top and err.max() <= 1e-2 * top, (err[solid].max(), err.max(), top)
     # argmax gathers are defined only where some weight is non-zero
     sel = g['cnl_weight'] > 1e-4
     same = np.abs(out['cnl_xyz'][sel] - g['cnl_xyz'][sel]).max(axis=-1) < 1e-4
