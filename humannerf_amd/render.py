@@ -1,11 +1,25 @@
-"""Frame-sharded rendering driver around the hot path ("next" row).
+"""Frame-sharded rendering driver and the image side of the path ("next" row).
 
-What run.py does per frame (run.py:68-157, 214-445): ``model(**data, iter_val=cfg.eval_iter)`` under
-no_grad, scatter the rendered rays back into the H x W image by ``ray_mask`` with background fill
-(run.py:48-65), quantise to 8 bit, write.  Here the scatter / quantisation runs on the GPU, frames are
-dealt round-robin over the ranks (one process per GPU, no data-path collective) and the finished
-uint8 images travel to the host asynchronously; rank 0 can gather them in frame order.
+What run.py does per frame (run.py:68-157, 214-445): ``model(**data, iter_val=cfg.eval_iter)`` under no_grad, scatter
+the rendered rays back into the H x W image by ``ray_mask`` with background fill (run.py:48-65), quantise to 8 bit,
+write PNGs / a video, append metrics.  Here the scatter / quantisation runs on the GPU, frames are dealt round-robin
+over the ranks (one process per GPU, no data-path collective), the finished uint8 images travel to the host
+asynchronously through pinned buffers and PNG encoding happens on worker threads, so that the GPU never waits for
+an image to be written.
+
+  unpack_to_image, to_8b_image, to_8b3ch_image, tile_images   run.py:37-65, image_util.py:21-53   (byte-exact:
+                                                              tests/golden/image_unpack.npz, made by the reference)
+  psnr, MetricsWriter                                         metrics_util.py:9-88                (same fixture)
+  ssim                                                        metrics_util.py:90-106 calls skimage -- not importable
+                                                              here: the published algorithm, parity unpinned
+  ImageWriter                                                 image_util.py:55-128 (PNG via PIL; the MP4 of finalize()
+                                                              needs imageio, which is absent: frames + .npy instead)
 """
+import os
+import queue
+import threading
+from collections import defaultdict
+
 import numpy as np
 import torch
 
@@ -13,31 +27,237 @@ from . import dist as hdist
 from .config import cfg
 
 
-def unpack_to_image(width, height, ray_mask, bgcolor, rgb, alpha):
-    """Device-side restatement of run.py:48-65: returns (rgb uint8 (H,W,3), alpha uint8 (H,W,3)).
-    bgcolor in 0..1 like the reference's call sites pass it (run.py:127-131)."""
+# --------------------------------------------------------------------------------------------- image helpers
+def to_8b_image(image):
+    """(255 * clip(image, 0, 1)) truncated to uint8 (image_util.py:21-22); numpy array or tensor."""
+    if torch.is_tensor(image):
+        return (255.0 * image.clamp(0.0, 1.0)).to(torch.uint8)
+    return (255. * np.clip(image, 0., 1.)).astype(np.uint8)
+
+
+def to_3ch_image(image):
+    """(H, W) or (H, W, 1) -> (H, W, 3) (image_util.py:25-33)."""
+    if torch.is_tensor(image):
+        if image.dim() == 2:
+            return torch.stack([image, image, image], dim=-1)
+        assert image.dim() == 3 and image.shape[2] == 1
+        return torch.cat([image, image, image], dim=-1)
+    if image.ndim == 2:
+        return np.stack([image, image, image], axis=-1)
+    assert image.ndim == 3 and image.shape[2] == 1
+    return np.concatenate([image, image, image], axis=-1)
+
+
+def to_8b3ch_image(image):
+    return to_3ch_image(to_8b_image(image))
+
+
+def tile_images(images, imgs_per_row=4):
+    """Mosaic of equally sized images, rows of ``imgs_per_row``; an incomplete last row is dropped, and so is a
+    last row that differs from the one before once there are more than two (image_util.py:40-53)."""
+    rows, row = [], []
+    imgs_per_row = min(len(images), imgs_per_row)
+    for img in images:
+        row.append(img)
+        if len(row) == imgs_per_row:
+            rows.append(np.concatenate(row, axis=1))
+            row = []
+    if len(rows) > 2 and len(rows[-1]) != len(rows[-2]):
+        rows.pop()
+    return np.concatenate(rows, axis=0)
+
+
+def unpack_to_image(width, height, ray_mask, bgcolor, rgb, alpha, truth=None):
+    """Device-side restatement of run.py:48-65.  ``bgcolor`` in 0..1 like the reference's call sites pass it
+    (run.py:127-131); ``rgb`` (N, 3), ``alpha`` (N,), optional ``truth`` (N, 3) for the rays selected by ``ray_mask``
+    (H*W,) bool.  Returns (rgb uint8 (H,W,3), alpha uint8 (H,W,3), truth uint8 (H,W,3)); without ``truth`` the third
+    entry is the float32 (H*W, 3) background plane, as in the reference."""
     dev = rgb.device
-    img = torch.as_tensor(bgcolor, dtype=torch.float32, device=dev).reshape(1, 3).repeat(height * width, 1)
-    img[ray_mask] = rgb
+    bg = torch.as_tensor(bgcolor, dtype=torch.float32, device=dev).reshape(1, 3)
+    ray_mask = torch.as_tensor(ray_mask, device=dev)
+    img = bg.repeat(height * width, 1)
+    img[ray_mask] = rgb.to(torch.float32)
+    rgb8 = to_8b_image(img).reshape(height, width, 3)
+    truth_img = bg.repeat(height * width, 1)
+    if truth is not None:
+        truth_img[ray_mask] = torch.as_tensor(truth, dtype=torch.float32, device=dev)
+        truth_img = to_8b_image(truth_img).reshape(height, width, 3)
     amap = torch.zeros(height * width, dtype=torch.float32, device=dev)
-    amap[ray_mask] = alpha
-    to8 = lambda x: (255.0 * x.clamp(0.0, 1.0)).to(torch.uint8)          # image_util.to_8b_image
-    rgb8 = to8(img).reshape(height, width, 3)
-    a8 = to8(amap).reshape(height, width, 1).expand(height, width, 3).contiguous()
-    return rgb8, a8
+    amap[ray_mask] = alpha.to(torch.float32)
+    a8 = to_8b3ch_image(amap.reshape(height, width)).contiguous()
+    return rgb8, a8, truth_img
 
 
-def psnr(pred, target):
-    """-10 log10(mse), maximum pixel value 1 (metrics_util.py:78-88)."""
+# --------------------------------------------------------------------------------------------- metrics
+def psnr(pred, target, mask=None):
+    """-10 log10(mse), maximum pixel value 1; optional (H, W, 1) bool mask tiled over the channels
+    (metrics_util.py:75-88)."""
+    if mask is not None:
+        mask = torch.tile(torch.as_tensor(mask), [1, 1, 3])
+        pred, target = pred[mask], target[mask]
     mse = ((pred - target) ** 2).mean()
     return -10.0 * torch.log(mse) / np.log(10.0)
 
 
-def render_frames(network, frames, rank=0, world=1, device=None, on_image=None):
+def ssim(pred, target, mask=None, data_range=1.0):
+    """Mean structural similarity (Wang et al. 2004) with the defaults skimage.metrics.structural_similarity uses for
+    float images: 7x7 uniform window, K1 = 0.01, K2 = 0.03, sample covariance, per-channel mean, borders cropped
+    by half a window; with ``mask`` the images are cropped to the mask's bounding box first (metrics_util.py:90-106).
+    PARITY UNPINNED: skimage is not importable in the build container, so no reference-generated vector exists."""
+    from scipy.ndimage import uniform_filter
+    a = np.asarray(pred.cpu() if torch.is_tensor(pred) else pred, dtype=np.float64)
+    b = np.asarray(target.cpu() if torch.is_tensor(target) else target, dtype=np.float64)
+    assert a.shape == b.shape
+    if mask is not None:
+        m = np.asarray(mask.cpu() if torch.is_tensor(mask) else mask).reshape(a.shape[0], a.shape[1]) != 0
+        ys, xs = np.where(m)
+        a, b = a[ys.min():ys.max() + 1, xs.min():xs.max() + 1], b[ys.min():ys.max() + 1, xs.min():xs.max() + 1]
+    win, k1, k2 = 7, 0.01, 0.03
+    c1, c2 = (k1 * data_range) ** 2, (k2 * data_range) ** 2
+    cov_norm = win * win / (win * win - 1.0)
+    vals = []
+    for ch in range(a.shape[2] if a.ndim == 3 else 1):
+        x, y = (a[..., ch], b[..., ch]) if a.ndim == 3 else (a, b)
+        ux, uy = uniform_filter(x, win), uniform_filter(y, win)
+        uxx, uyy, uxy = uniform_filter(x * x, win), uniform_filter(y * y, win), uniform_filter(x * y, win)
+        vx, vy, vxy = cov_norm * (uxx - ux * ux), cov_norm * (uyy - uy * uy), cov_norm * (uxy - ux * uy)
+        s = ((2 * ux * uy + c1) * (2 * vxy + c2)) / ((ux ** 2 + uy ** 2 + c1) * (vx + vy + c2))
+        pad = (win - 1) // 2
+        vals.append(s[pad:s.shape[0] - pad, pad:s.shape[1] - pad].mean())
+    return float(np.mean(vals))
+
+
+class MetricsWriter:
+    """Per-image and average metric text files in the reference's format (metrics_util.py:9-60): ``<exp>-metrics.
+    perimg.txt`` gets ``name: psnr-26.2530 ssim-0.9123 `` per image, ``<exp>-metrics.average.txt`` gets
+    ``p:26.3092`` (first letter of the metric).  ``metrics`` defaults to cfg.eval.metrics or ['psnr']; 'lpips' needs a
+    caller-supplied ``lpips_fn(pred, target)`` (the VGG trunk cannot be fetched offline)."""
+
+    def __init__(self, output_dir, exp_name, dataset, metrics=None, lpips_fn=None):
+        os.makedirs(output_dir, exist_ok=True)
+        self.per_img_f = open(os.path.join(output_dir, '%s-metrics.perimg.txt' % exp_name), 'a')
+        self.average_f = open(os.path.join(output_dir, '%s-metrics.average.txt' % exp_name), 'a')
+        self.per_img_f.writelines('=========%s==========\n' % dataset)
+        self.average_f.writelines('=========%s==========\n' % dataset)
+        self.metrics = list(metrics if metrics is not None else cfg.get('eval', {}).get('metrics', ['psnr']))
+        if 'lpips' in self.metrics and lpips_fn is None:
+            raise ValueError('metric lpips needs an lpips_fn (LPIPS-VGG weights are not obtainable offline)')
+        self.funcs = {'psnr': lambda p, t, m: psnr(p, t, m).item(),
+                      'ssim': lambda p, t, m: ssim(p, t, m),
+                      'lpips': lambda p, t, m: 1000 * float(lpips_fn(p, t))}
+        self.name2metrics, self.sums, self.N = {}, defaultdict(float), 0
+
+    @staticmethod
+    def normalize(img):
+        if isinstance(img, np.ndarray):
+            img = torch.tensor(img, dtype=torch.float32)
+        if torch.max(img) > 2:
+            img = img / 255
+        return img
+
+    def append(self, name, pred, target, mask=None):
+        self.N += 1
+        assert name not in self.name2metrics, name
+        pred, target = self.normalize(pred), self.normalize(target)
+        self.per_img_f.writelines('%s: ' % name)
+        self.name2metrics[name] = {}
+        for k in self.metrics:
+            v = self.funcs[k](pred, target, mask)
+            self.name2metrics[name][k] = v
+            self.sums[k] += v
+            self.per_img_f.writelines('{}-{:.4f} '.format(k, v))
+        self.per_img_f.writelines('\n')
+
+    def finalize(self):
+        averages = {k: v / self.N for k, v in self.sums.items()}
+        for k, v in averages.items():
+            self.average_f.writelines('%s:%.4f\n' % (k[0], v))
+        self.per_img_f.close()
+        self.average_f.close()
+        return averages
+
+
+class ImageWriter:
+    """PNG writer of the render drivers (image_util.py:55-128): ``<output_dir>/<exp_name>/<name or %06d>.png``.
+    Encoding runs on ``workers`` threads behind a bounded queue (PIL releases the GIL while it compresses), so
+    ``append`` returns at once and can be used as ``render_frames(on_image=...)``; ``finalize`` drains the queue.  The
+    reference's finalize() also writes an MP4 through imageio: imageio is not importable here, so the frames are
+    additionally stacked into ``<exp_name>.npy`` (sorted by name like the reference) and the encoder is left to the user."""
+
+    def __init__(self, output_dir, exp_name, workers=4, keep_frames=True):
+        from PIL import Image
+        self._Image = Image
+        self.output_dir = output_dir
+        self.image_dir = os.path.join(output_dir, exp_name)
+        os.makedirs(self.image_dir, exist_ok=True)
+        self.frame_idx = -1
+        self.keep = keep_frames
+        self.images_np, self.image_names = [], []
+        self._q = queue.Queue(maxsize=4 * workers)
+        self._err = []
+        self._threads = [threading.Thread(target=self._work, daemon=True) for _ in range(workers)]
+        for t in self._threads:
+            t.start()
+
+    def _work(self):
+        while True:
+            item = self._q.get()
+            if item is None:
+                return
+            try:
+                self._Image.fromarray(item[0]).save(item[1])
+            except Exception as e:               # surfaced by finalize()
+                self._err.append(e)
+
+    def append(self, image, img_name=None):
+        self.frame_idx += 1
+        if img_name is None:
+            img_name = '%06d' % self.frame_idx
+        image = np.ascontiguousarray(image)
+        self._q.put((image, os.path.join(self.image_dir, '%s.png' % img_name)))
+        if self.keep:
+            self.images_np.append(image)
+            self.image_names.append(img_name)
+        return self.frame_idx, img_name
+
+    def finalize(self, video_name=None):
+        for _ in self._threads:
+            self._q.put(None)
+        for t in self._threads:
+            t.join()
+        if self._err:
+            raise self._err[0]
+        if self.keep and self.images_np:
+            order = sorted(range(len(self.images_np)), key=lambda i: self.image_names[i])
+            stack = np.stack([self.images_np[i] for i in order], axis=0)
+            path = (self.image_dir.rstrip('/') + '.npy') if video_name is None else os.path.join(self.image_dir, video_name + '.npy')
+            np.save(path, stack)
+            return path
+        return None
+
+
+# --------------------------------------------------------------------------------------------- frame loop
+class _PinnedPool:
+    """A few page-locked uint8 staging buffers per image shape: device -> host copies into pageable memory are
+    staged and synchronous inside the runtime; into pinned memory they are real asynchronous DMA."""
+
+    def __init__(self):
+        self.free = defaultdict(list)
+
+    def take(self, shape):
+        lst = self.free[tuple(shape)]
+        return lst.pop() if lst else torch.empty(tuple(shape), dtype=torch.uint8, pin_memory=True)
+
+    def give(self, t):
+        self.free[tuple(t.shape)].append(t)
+
+
+def render_frames(network, frames, rank=0, world=1, device=None, on_image=None, show_truth=False):
     """Render ``frames`` (sequence of per-frame input dicts, numpy or tensors) frame-sharded.
 
-    Returns {frame_idx: uint8 rgb image on the host} for this rank's frames.  ``on_image(idx, rgb8,
-    alpha8)`` is called as images arrive (e.g. a PNG writer thread).
+    Returns {frame_idx: uint8 rgb image on the host} for this rank's frames.  ``on_image(idx, rgb8, alpha8[,
+    truth8])`` is called as images arrive (e.g. ``ImageWriter.append``); with ``show_truth`` a frame's ``target_rgbs``
+    (N, 3) are unpacked next to the render (run.py:131-136) and handed over as the fourth argument.
 
     A frame may carry its camera instead of precomputed rays -- ``K`` (3,3), ``E`` (4,4), ``cnl_bbox_max_xyz`` next to
     ``img_width`` / ``img_height`` and no ``rays``: the rays, near/far and ray_mask are then generated on the
@@ -50,9 +270,24 @@ def render_frames(network, frames, rank=0, world=1, device=None, on_image=None):
     old = cfg.perturb
     cfg.perturb = 0.                                                     # run.py:71,215
     out = {}
-    copy_stream = torch.cuda.Stream(device=device) if device.type == 'cuda' else None
+    on_gpu = device.type == 'cuda'
+    copy_stream = torch.cuda.Stream(device=device) if on_gpu else None
+    pool = _PinnedPool()
     pending = []
     resident = {}                                                        # key -> (host array, device tensor)
+
+    def deliver(item):
+        i, hosts, e = item
+        if e is not None:
+            e.synchronize()
+        arrs = [h.numpy().copy() if on_gpu else h.numpy() for h in hosts]
+        if on_gpu:
+            for h in hosts:
+                pool.give(h)
+        out[i] = arrs[0]
+        if on_image is not None:
+            on_image(i, *arrs)
+
     try:
         for idx in hdist.frame_shard(len(frames), rank, world):
             fr = frames[idx]
@@ -77,32 +312,30 @@ def render_frames(network, frames, rank=0, world=1, device=None, on_image=None):
             with torch.no_grad():
                 res = network(**data, iter_val=float(cfg.eval_iter))
             mask = torch.as_tensor(fr['ray_mask']).to(device)
-            rgb8, a8 = unpack_to_image(int(fr['img_width']), int(fr['img_height']), mask, data['bgcolor'] / 255.,
-                                       res['rgb'], res['alpha'])
-            if copy_stream is not None:                                  # overlap D2H with the next frame
+            truth = None
+            if show_truth and fr.get('target_rgbs', None) is not None:
+                truth = torch.as_tensor(fr['target_rgbs']).to(device)
+            rgb8, a8, t8 = unpack_to_image(int(fr['img_width']), int(fr['img_height']), mask, data['bgcolor'] / 255.,
+                                           res['rgb'], res['alpha'], truth)
+            imgs = [rgb8, a8] + ([t8] if truth is not None else [])
+            if on_gpu:                                                   # overlap D2H with the next frame
                 copy_stream.wait_stream(torch.cuda.current_stream(device))
+                hosts = []
                 with torch.cuda.stream(copy_stream):
-                    host = (rgb8.to('cpu', non_blocking=True), a8.to('cpu', non_blocking=True))
+                    for im in imgs:
+                        h = pool.take(im.shape)
+                        h.copy_(im, non_blocking=True)
+                        im.record_stream(copy_stream)
+                        hosts.append(h)
                     ev = torch.cuda.Event()
                     ev.record(copy_stream)
-                rgb8.record_stream(copy_stream)
-                a8.record_stream(copy_stream)
-                pending.append((idx, host, ev))
+                pending.append((idx, hosts, ev))
             else:
-                pending.append((idx, (rgb8.cpu(), a8.cpu()), None))
+                pending.append((idx, [im.cpu() for im in imgs], None))
             while pending and (pending[0][2] is None or pending[0][2].query() or len(pending) > 2):
-                i, (h_rgb, h_a), e = pending.pop(0)
-                if e is not None:
-                    e.synchronize()
-                out[i] = h_rgb.numpy()
-                if on_image is not None:
-                    on_image(i, out[i], h_a.numpy())
-        for i, (h_rgb, h_a), e in pending:
-            if e is not None:
-                e.synchronize()
-            out[i] = h_rgb.numpy()
-            if on_image is not None:
-                on_image(i, out[i], h_a.numpy())
+                deliver(pending.pop(0))
+        while pending:
+            deliver(pending.pop(0))
     finally:
         cfg.perturb = old
     return out

@@ -18,14 +18,28 @@ def dev():
     return torch.device('cuda:0')
 
 
-@pytest.mark.parametrize('train_mode,rel_norm,cos_min', [('f32', 2e-3, 0.9995), ('f16x3', 2e-3, 0.9995)])
-def test_network_gradients_match_reference(train_mode, rel_norm, cos_min, seeded_params, golden_dir):
-    """Gradients of all 55 parameter tensors vs the REFERENCE's own loss.backward() (tests/golden/grad_s64.npz), with
-    the training kernels in exact-fp32 MFMA arithmetic and in the default split-f16 arithmetic, at the bound the
-    CPU oracle itself meets (tests/test_grad_oracle.py).  The printed worst-case numbers are what split-f16 costs on
-    end-to-end gradients."""
+@pytest.fixture(scope='module')
+def exact_gradients(seeded_params, golden_dir):
+    """fp64 torch.autograd through the oracle for the gradient fixture's frame and loss (CPU, ~20 s)."""
+    from tests.test_grad_oracle import oracle_gradients
+    with open(os.path.join(golden_dir, 'meta.json')) as f:
+        meta = json.load(f)['grad_s64']
+    g = np.load(os.path.join(golden_dir, 'grad_s64.npz'))
+    return oracle_gradients(seeded_params, meta, g, torch.float64)[0]
+
+
+@pytest.mark.parametrize('train_mode', ['f32', 'f16x3'])
+def test_network_gradients_match_reference(train_mode, seeded_params, golden_dir, exact_gradients):
+    """Gradients of all 55 parameter tensors, with the training kernels in exact-fp32 MFMA arithmetic and in the
+    default split-f16 arithmetic,
+      * vs the REFERENCE's own loss.backward() (tests/golden/grad_s64.npz) at the reference's noise floor: its fp32
+        gradients are up to 4.4e-3 (norm) away from an fp64 evaluation (tests/test_grad_oracle.py), so 6e-3 / cosine
+        0.99998 is what can be asked against it;
+      * vs that fp64 evaluation (torch.autograd through the oracle), tightly -- this is where a cost of the split-f16
+        arithmetic on end-to-end gradients would show, and the printed numbers are that cost."""
     from humannerf_amd.config import cfg
     from humannerf_amd.network import Network
+    from tests.test_grad_oracle import compare_exact
     with open(os.path.join(golden_dir, 'meta.json')) as f:
         meta = json.load(f)['grad_s64']
     g = np.load(os.path.join(golden_dir, 'grad_s64.npz'))
@@ -49,8 +63,9 @@ def test_network_gradients_match_reference(train_mode, rel_norm, cos_min, seeded
     assert abs(float(loss) - meta['loss']) <= 2e-4 * max(1.0, abs(meta['loss']))
     grads = {k: (p.grad.cpu().numpy() if p.grad is not None else np.zeros(tuple(p.shape), np.float32))
              for k, p in net.named_parameters()}
-    stats = compare_grads(grads, g, rel_norm=rel_norm, cos_min=cos_min)
-    print('gradients vs reference, training arithmetic', train_mode, stats, 'loss err', abs(float(loss) - meta['loss']))
+    vs_ref = compare_grads(grads, g, rel_norm=6e-3, cos_min=0.99998)
+    vs_exact = compare_exact(grads, exact_gradients, rel_norm=5e-4, cos_min=0.999995)
+    print('gradients, training arithmetic', train_mode, '| vs reference', vs_ref, '| vs fp64', vs_exact)
 
 
 def test_composite_bwd_kernel():

@@ -568,3 +568,50 @@ def test_early_ray_termination_evaluates_fewer_samples():
     assert 0 < n_eval < R * S // 2, n_eval
     assert float((out['rgb'] - dense['rgb']).abs().max()) <= 2e-4
     assert float((out['alpha'] - dense['alpha']).abs().max()) <= 2e-4
+
+
+def test_image_unpack_on_device_matches_reference_bytes(golden_dir):
+    """render.unpack_to_image on the GPU vs what the reference's run.unpack_to_image returned (tests/golden/
+    image_unpack.npz): rgb, alpha and truth images byte for byte, three background colours."""
+    from tests.test_image_side import check_unpack
+    check_unpack(np.load(os.path.join(golden_dir, 'image_unpack.npz')), dev())
+
+
+def test_render_frames_writes_pngs_and_truth(gpu_net, tmp_path):
+    """run.py:68-157 end to end on synthetic frames: render -> device-side unpack -> pinned async D2H -> threaded PNG
+    writer; the images on disk are the images returned, the truth image is the scattered ``target_rgbs``, and what was
+    rendered equals Network.forward's rgb quantised like the reference does."""
+    from PIL import Image
+    from humannerf_amd import render, scene
+    from humannerf_amd.config import cfg
+    frames = [scene.synthetic_frame(H=64, W=48, focal_at_512=1250.0, pose_seed=s, bgcolor=(30., 120., 250.)) for s in range(4)]
+    rs = np.random.RandomState(2)
+    for fr in frames:
+        fr['target_rgbs'] = rs.rand(fr['rays'].shape[1], 3).astype(np.float32)
+    writer = render.ImageWriter(str(tmp_path), 'freeview', workers=2)
+    got = {}
+
+    def on_image(i, rgb8, a8, t8):
+        got[i] = (rgb8, a8, t8)
+        writer.append(np.concatenate([rgb8, t8, a8], axis=1), img_name='%06d' % i)      # run.py:131-140 layout
+    cfg.amd.diagnostics = False
+    try:
+        imgs = render.render_frames(gpu_net, frames, on_image=on_image, show_truth=True)
+        with torch.no_grad():
+            cfg.perturb = 0.
+            direct = gpu_net(**frame_to_gpu(frames[2]), iter_val=float(cfg.eval_iter))
+    finally:
+        cfg.amd.diagnostics, cfg.perturb = True, 1.0
+    writer.finalize()
+    assert sorted(imgs) == [0, 1, 2, 3] and sorted(got) == [0, 1, 2, 3]
+    for i, fr in enumerate(frames):
+        H, W = 64, 48
+        on_disk = np.asarray(Image.open(tmp_path / 'freeview' / ('%06d.png' % i)))
+        assert on_disk.shape == (H, 3 * W, 3)
+        assert np.array_equal(on_disk[:, :W], imgs[i]) and np.array_equal(on_disk[:, W:2 * W], got[i][2])
+        truth = np.full((H * W, 3), np.array([30., 120., 250.], np.float32) / 255., np.float32)
+        truth[fr['ray_mask']] = fr['target_rgbs']
+        assert np.array_equal(got[i][2], render.to_8b_image(truth.reshape(H, W, 3)))
+    ref = np.full((64 * 48, 3), np.array([30., 120., 250.], np.float32) / 255., np.float32)
+    ref[frames[2]['ray_mask']] = direct['rgb'].cpu().numpy()
+    assert np.array_equal(imgs[2], render.to_8b_image(ref.reshape(64, 48, 3)))

@@ -13,11 +13,14 @@ KEYS = ['rays', 'near', 'far', 'dst_Rs', 'dst_Ts', 'cnl_gtfms', 'motion_weights_
 
 
 def _oracle_steps(state, fr, target, t_rand, iters, n_samples, lrs):
-    """The reference's iteration on the CPU: 0.2*MSE (trainer.py:97-113 without LPIPS), Adam with one group per tensor."""
+    """The reference's iteration on the CPU in fp64: 0.2*MSE (trainer.py:97-113 without LPIPS), Adam with one group per
+    tensor.  fp64 because the fp32 gradients of the reference arithmetic are themselves ~0.4 % noisy
+    (tests/test_grad_oracle.py::test_reference_gradient_noise_floor), and Adam's first steps amplify gradient noise
+    on small elements into whole step sizes."""
     from oracle import oracle
     from humannerf_amd.train import customized_lr_names
     from humannerf_amd.config import cfg
-    params = {k: torch.from_numpy(v).clone().requires_grad_(True) for k, v in state.items()}
+    params = {k: torch.from_numpy(v).double().requires_grad_(True) for k, v in state.items()}
     groups = []
     for k, p in params.items():
         hit = [n for n in customized_lr_names() if n in k]
@@ -26,8 +29,8 @@ def _oracle_steps(state, fr, target, t_rand, iters, n_samples, lrs):
     losses = []
     for it in iters:
         opt.zero_grad()
-        out = oracle.render(params, fr, iter_val=float(it), N_samples=n_samples, t_rand=t_rand)
-        loss = 0.2 * torch.mean((out['rgb'] - torch.from_numpy(target)) ** 2)
+        out = oracle.render(params, fr, iter_val=float(it), N_samples=n_samples, t_rand=t_rand, dtype=torch.float64)
+        loss = 0.2 * torch.mean((out['rgb'] - torch.from_numpy(target).double()) ** 2)
         loss.backward()
         opt.step()
         decay = 0.1 ** (it / (cfg.train.lrate_decay * 1000))
@@ -76,7 +79,7 @@ def test_two_optimizer_steps_match_oracle_adam(seeded_params):
     # gradient is within fp32 noise of zero may legitimately move the other way, by at most ~2 lr per step -- so the
     # bound on single elements is the step size, and what is pinned tightly is the bulk: relative L2 distance of the
     # accumulated update, and the fraction of elements that moved differently
-    worst = (0.0, None)
+    worst, worst_frac = (0.0, None), (0.0, None)
     for k in want:
         lr = 5e-5 if any(n in k for n in ('mweight_vol_decoder', 'pose_decoder', 'non_rigid_mlp')) else 5e-4
         before = seeded_params[k]
@@ -87,9 +90,9 @@ def test_two_optimizer_steps_match_oracle_adam(seeded_params):
         if moved.sum() > 100:
             frac_off = float((diff[moved] > 0.05 * lr).mean())
             rel_l2 = float(np.linalg.norm((du - du_ref)[moved]) / np.linalg.norm(du_ref[moved]))
-            worst = max(worst, (rel_l2, k))
+            worst, worst_frac = max(worst, (rel_l2, k)), max(worst_frac, (frac_off, k))
             assert frac_off <= 2e-2 and rel_l2 <= 0.1, (k, frac_off, rel_l2)
-    print('worst relative L2 distance of the 3-step update', worst)
+    print('3-step update vs fp64 oracle: worst relative L2 distance', worst, 'worst fraction of elements off by > 5 % of lr', worst_frac)
 
 
 def test_train_loop_checkpoints_and_progress(tmp_path, seeded_params):
