@@ -1,0 +1,294 @@
+"""On-disk formats of the reference and the per-frame input assembly in front of the path
+(SURVEY.md section 8(f) rank 4 + the caller side of rank 1).
+
+A prepared subject directory (tools/prepare_zju_mocap/prepare_dataset.py:172-221, tools/prepare_wild/
+prepare_dataset.py:82-111) holds
+
+    cameras.pkl           {frame: {'intrinsics' (3,3), 'extrinsics' (4,4) [, 'distortions' (5,)]}}
+    mesh_infos.pkl        {frame: {'Rh' (3,), 'Th' (3,), 'poses' (72,), 'joints' (24,3), 'tpose_joints' (24,3)}}
+    canonical_joints.pkl  {'joints': (24,3)}
+    images/<frame>.png, masks/<frame>.png
+
+written with ``pickle.dump`` of plain dicts of numpy arrays.  ``load_array_pickle`` reads them with an unpickler that
+can build nothing but numpy arrays / scalars and builtin containers -- a dataset file cannot run code here.
+Checkpoints (``.tar`` = torch.save of {'iter', 'network', 'optimizer'}, trainer.py:356-364) are read by
+``train.load_checkpoint`` with ``weights_only=True``.
+
+``Subject`` mirrors what the reference's Dataset classes hold per subject (core/data/human_nerf/train.py:40-135,
+freeview.py:32-118); ``movement_frame`` / ``freeview_frame`` / ``train_frame`` assemble the dict one
+``Dataset.__getitem__`` yields (train.py:481-755, freeview.py:172-280) -- by default WITHOUT the per-pixel numpy
+pass: the frame carries its camera and posed bbox, and ``render.render_frames`` / ``ops.gen_rays`` produce rays,
+near / far and ray_mask on the device.  ``host_rays=True`` runs the reference's numpy route (scene.py) instead.
+
+cv2 is not importable here.  What the reference does through it:
+  * cv2.Rodrigues (camera_util.py:39, 128): restated by the closed form (``rodrigues_cv``), PARITY UNPINNED
+    against OpenCV's own numerics (agrees with the formula to rounding);
+  * cv2.undistort (train.py:355-358): frames whose camera has non-zero ``distortions`` raise;
+  * cv2.resize LANCZOS4 / LINEAR (train.py:400-408): only ``resize_img_scale == 1`` is loaded bit-exactly; other scales
+    go through PIL's Lanczos / bilinear filters and are flagged ``resize_parity='unpinned'`` in the frame.
+"""
+import io
+import os
+import pickle
+
+import numpy as np
+
+from . import scene
+from .config import cfg
+
+# ------------------------------------------------------------------------------------------------ safe pickle reader
+_NUMPY_GLOBALS = {
+    ('numpy.core.multiarray', '_reconstruct'), ('numpy._core.multiarray', '_reconstruct'),
+    ('numpy.core.multiarray', 'scalar'), ('numpy._core.multiarray', 'scalar'),
+    ('numpy', 'ndarray'), ('numpy', 'dtype'),
+    ('numpy.core.numeric', '_frombuffer'), ('numpy._core.numeric', '_frombuffer'),
+}
+_BUILTIN_GLOBALS = {('collections', 'OrderedDict'), ('builtins', 'dict'), ('builtins', 'list'), ('builtins', 'tuple'),
+                    ('builtins', 'set'), ('builtins', 'frozenset'), ('builtins', 'slice'), ('builtins', 'complex'),
+                    ('builtins', 'bytearray')}
+
+
+class _ArrayUnpickler(pickle.Unpickler):
+    """Unpickler whose only reachable globals build numpy arrays / scalars / dtypes and builtin containers."""
+
+    def find_class(self, module, name):
+        if (module, name) in _NUMPY_GLOBALS:
+            import numpy._core.multiarray as ma
+            import numpy._core.numeric as nu
+            return {'_reconstruct': ma._reconstruct, 'scalar': ma.scalar, 'ndarray': np.ndarray, 'dtype': np.dtype,
+                    '_frombuffer': nu._frombuffer}[name]
+        if (module, name) in _BUILTIN_GLOBALS:
+            import builtins
+            import collections
+            return getattr(collections if module == 'collections' else builtins, name)
+        raise pickle.UnpicklingError('refusing to load %s.%s: dataset pickles may only contain numpy arrays and '
+                                     'builtin containers' % (module, name))
+
+
+def load_array_pickle(path_or_bytes):
+    if isinstance(path_or_bytes, (bytes, bytearray)):
+        return _ArrayUnpickler(io.BytesIO(path_or_bytes)).load()
+    with open(path_or_bytes, 'rb') as f:
+        return _ArrayUnpickler(f).load()
+
+
+# ------------------------------------------------------------------------------------------------ camera helpers
+def rodrigues_cv(rvec):
+    """What cv2.Rodrigues(rvec)[0] computes: R = cos t I + (1 - cos t) r r^T + sin t [r]_x, r = rvec / t, t = |rvec|
+    (identity for t = 0), float64.  Unlike body_util's variant there is no +1e-5 in the normalisation."""
+    rvec = np.asarray(rvec, dtype=np.float64).reshape(3)
+    theta = np.linalg.norm(rvec)
+    if theta < np.finfo(np.float64).eps:
+        return np.eye(3)
+    r = rvec / theta
+    K = np.array([[0, -r[2], r[1]], [r[2], 0, -r[0]], [-r[1], r[0], 0]])
+    return np.cos(theta) * np.eye(3) + (1.0 - np.cos(theta)) * np.outer(r, r) + np.sin(theta) * K
+
+
+def apply_global_tfm_to_camera(E, Rh, Th):
+    """Extrinsics in the frame of the body's root (camera_util.py:117-131)."""
+    g = np.eye(4)
+    rot = rodrigues_cv(Rh).T
+    g[:3, :3] = rot
+    g[:3, 3] = -rot.dot(np.asarray(Th, dtype=np.float64))
+    return np.asarray(E).dot(np.linalg.inv(g))
+
+
+def rotate_camera_by_frame_idx(extrinsics, frame_idx, trans=None, rotate_axis='y', period=196, inv_angle=False):
+    """Orbit of the free-viewpoint renderer (camera_util.py:6-48, 82-114)."""
+    angle = 2 * np.pi * (frame_idx / period)
+    if inv_angle:
+        angle = -angle
+    inv_E = np.linalg.inv(extrinsics)
+    camrot, campos = inv_E[:3, :3], inv_E[:3, 3].copy()
+    if trans is not None:
+        campos -= trans
+    if camrot.T[1, 1] < 0.:
+        angle = -angle
+    vec = np.zeros(3)
+    vec[{'x': 0, 'y': 1, 'z': 2}[rotate_axis]] = angle
+    grot = rodrigues_cv(vec).astype('float32')
+    rot_campos, rot_camrot = grot.dot(campos), grot.dot(camrot)
+    if trans is not None:
+        rot_campos += trans
+    new_E = np.identity(4)
+    new_E[:3, :3] = rot_camrot.T
+    new_E[:3, 3] = -rot_camrot.T.dot(rot_campos)
+    return new_E
+
+
+def skeleton_to_bbox(skeleton, offset=None):
+    """train.py:118-126."""
+    offset = cfg.bbox_offset if offset is None else offset
+    return {'min_xyz': np.min(skeleton, axis=0) - offset, 'max_xyz': np.max(skeleton, axis=0) + offset}
+
+
+ROT_CAM_PARAMS = {'zju_mocap': {'rotate_axis': 'z', 'inv_angle': True},
+                  'wild': {'rotate_axis': 'y', 'inv_angle': False}}            # freeview.py:26-29
+
+
+# ------------------------------------------------------------------------------------------------ subject
+class Subject:
+    """Everything the reference's Dataset.__init__ loads for one prepared subject directory."""
+
+    def __init__(self, dataset_path, skip=1, maxframes=-1, volume_size=None, require_images=False):
+        self.dataset_path = dataset_path
+        self.image_dir = os.path.join(dataset_path, 'images')
+        joints = load_array_pickle(os.path.join(dataset_path, 'canonical_joints.pkl'))['joints']
+        self.canonical_joints = joints.astype('float32')
+        self.canonical_bbox = skeleton_to_bbox(self.canonical_joints)
+        self.cameras = load_array_pickle(os.path.join(dataset_path, 'cameras.pkl'))
+        self.mesh_infos = load_array_pickle(os.path.join(dataset_path, 'mesh_infos.pkl'))
+        for info in self.mesh_infos.values():
+            info['bbox'] = skeleton_to_bbox(info['joints'])
+        g = int(volume_size or cfg.mweight_volume.volume_size)
+        self.motion_weights_priors = scene.approx_gaussian_bone_volumes(
+            self.canonical_joints, self.canonical_bbox['min_xyz'], self.canonical_bbox['max_xyz'], grid_size=g).astype('float32')
+        self.cnl_gtfms = scene.get_canonical_global_tfms(self.canonical_joints)
+        if os.path.isdir(self.image_dir):                   # the reference lists images/*.png (train.py:172-176)
+            frames = sorted(os.path.splitext(f)[0] for f in os.listdir(self.image_dir) if f.endswith('.png'))
+        elif require_images:
+            raise FileNotFoundError(self.image_dir)
+        else:
+            frames = list(self.mesh_infos.keys())
+        self.framelist_all = frames
+        self.framelist = frames[::skip]
+        if maxframes > 0:
+            self.framelist = self.framelist[:maxframes]
+
+    def __len__(self):
+        return len(self.framelist)
+
+    # -- pieces shared by every frame kind ------------------------------------------------------------------
+    def _skeleton_entries(self, info):
+        poses = info['poses'].astype('float32')
+        dst_Rs, dst_Ts = scene.body_pose_to_body_RTs(poses, info['tpose_joints'].astype('float32'))
+        mn = self.canonical_bbox['min_xyz'].astype('float32')
+        mx = self.canonical_bbox['max_xyz'].astype('float32')
+        scale = 2.0 / (mx - mn)
+        assert np.all(scale >= 0)
+        return {'dst_Rs': dst_Rs, 'dst_Ts': dst_Ts, 'cnl_gtfms': self.cnl_gtfms,
+                'motion_weights_priors': self.motion_weights_priors,      # same array object every frame: the
+                'cnl_bbox_min_xyz': mn, 'cnl_bbox_max_xyz': mx,           # renderer keeps it resident by identity
+                'cnl_bbox_scale_xyz': scale, 'dst_posevec': poses[3:] + 1e-2}
+
+    def _camera_entries(self, K, E, info, H, W, host_rays):
+        """K already scaled to the image size; E with the global transform applied."""
+        bbox = info['bbox']
+        out = {'img_width': int(W), 'img_height': int(H)}
+        if not host_rays:
+            out.update(K=K.astype('float32'), E=E.astype('float32'),
+                       ray_bbox_min_xyz=np.asarray(bbox['min_xyz'], 'float32'),
+                       ray_bbox_max_xyz=np.asarray(bbox['max_xyz'], 'float32'))
+            return out
+        rays_o, rays_d = scene.get_rays_from_KRT(H, W, K, E[:3, :3], E[:3, 3])
+        rays_o, rays_d = rays_o.reshape(-1, 3).copy(), rays_d.reshape(-1, 3).copy()
+        near, far, ray_mask = scene.rays_intersect_3d_bbox(bbox, rays_o, rays_d)
+        rays_o, rays_d = rays_o[ray_mask], rays_d[ray_mask]
+        out.update(rays=np.stack([rays_o, rays_d, rays_d], axis=0).astype('float32'),      # [o, d, d_camera]: SURVEY 2.3
+                   near=near[:, None].astype('float32'), far=far[:, None].astype('float32'), ray_mask=ray_mask)
+        return out
+
+    # -- frame kinds ------------------------------------------------------------------------------------------
+    def movement_frame(self, idx, bgcolor=None, host_rays=False, image_size=None, load_image=False):
+        """What the train dataset yields in ray_shoot_mode 'image' (movement / progress renders,
+        train.py:481-755): the frame's own camera and pose.  ``image_size`` (H, W) is needed when the image is
+        not loaded (camera-only rendering)."""
+        name = self.framelist[idx]
+        info, cam = self.mesh_infos[name], self.cameras[name]
+        bg = np.array(cfg.bgcolor if bgcolor is None else bgcolor, dtype='float32')
+        out = {'frame_name': name, 'bgcolor': bg}
+        img = None
+        if load_image:
+            img, alpha, flag = self.load_image(name, bg)
+            img = (img / 255.).astype('float32')
+            H, W = img.shape[:2]
+            out['resize_parity'] = flag
+        else:
+            H, W = image_size
+        K = cam['intrinsics'][:3, :3].copy()
+        K[:2] *= cfg.get('resize_img_scale', 1.0)
+        E = apply_global_tfm_to_camera(cam['extrinsics'], info['Rh'].astype('float32'), info['Th'].astype('float32'))
+        out.update(self._camera_entries(K, E, info, H, W, host_rays))
+        out.update(self._skeleton_entries(info))
+        if img is not None:
+            out['raw_rgbs'] = img
+            if host_rays:
+                out['target_rgbs'] = img.reshape(-1, 3)[out['ray_mask']]
+        return out
+
+    def freeview_frame(self, idx, total_frames, train_frame_idx=0, src_type='zju_mocap', bgcolor=None, host_rays=False,
+                       image_size=None):
+        """freeview.py:172-280: the training frame ``train_frame_idx`` seen from a camera orbiting the subject."""
+        name = self.framelist_all[train_frame_idx]
+        info, cam = self.mesh_infos[name], self.cameras[name]
+        Th = info['Th'].astype('float32')
+        E = rotate_camera_by_frame_idx(cam['extrinsics'], idx, trans=Th, period=total_frames, **ROT_CAM_PARAMS[src_type])
+        K = cam['intrinsics'].copy()
+        K[:2] *= cfg.get('resize_img_scale', 1.0)
+        E = apply_global_tfm_to_camera(E, info['Rh'].astype('float32'), Th)
+        H, W = image_size
+        out = {'frame_name': name, 'bgcolor': np.array([255., 255., 255.] if bgcolor is None else bgcolor, dtype='float32')}
+        out.update(self._camera_entries(K, E, info, H, W, host_rays))
+        out.update(self._skeleton_entries(info))
+        return out
+
+    def train_frame(self, idx, bgcolor=None):
+        """One training item (ray_shoot_mode 'patch', train.py:481-631): image + mask from disk, rays of
+        cfg.patch.N_patches windows of cfg.patch.size^2 pixels drawn by the reference's sampler (global numpy generator),
+        target patches and their masks.  Background: random colour per item when ``bgcolor`` is None (train.py:513-516)."""
+        name = self.framelist[idx]
+        info, cam = self.mesh_infos[name], self.cameras[name]
+        bg = (np.random.rand(3) * 255.).astype('float32') if bgcolor is None else np.array(bgcolor, dtype='float32')
+        img, alpha, flag = self.load_image(name, bg)
+        img = (img / 255.).astype('float32')
+        H, W = img.shape[:2]
+        K = cam['intrinsics'][:3, :3].copy()
+        K[:2] *= cfg.get('resize_img_scale', 1.0)
+        E = apply_global_tfm_to_camera(cam['extrinsics'], info['Rh'].astype('float32'), info['Th'].astype('float32'))
+        ent = self._camera_entries(K, E, info, H, W, host_rays=True)
+        ray_mask = ent['ray_mask']
+        sel, pinfo, div = scene.sample_patch_rays(ray_mask, alpha[:, :, 0] > 0., ray_mask.reshape(H, W),
+                                                  int(cfg.patch.N_patches), int(cfg.patch.size), H, W,
+                                                  subject_ratio=float(cfg.patch.sample_subject_ratio))
+        targets = np.stack([img[y0:y1, x0:x1] for (x0, y0), (x1, y1) in zip(pinfo['xy_min'], pinfo['xy_max'])], axis=0)
+        out = {'frame_name': name, 'bgcolor': bg, 'img_width': W, 'img_height': H, 'ray_mask': ray_mask,
+               'rays': ent['rays'][:, sel], 'near': ent['near'][sel], 'far': ent['far'][sel],
+               'patch_div_indices': div, 'patch_masks': pinfo['mask'], 'target_patches': targets,
+               'target_rgbs': img.reshape(-1, 3)[ray_mask][sel], 'resize_parity': flag}
+        out.update(self._skeleton_entries(info))
+        return out
+
+    # -- images -------------------------------------------------------------------------------------------------
+    def load_image(self, frame_name, bg_color):
+        """train.py:351-408 (default branches): alpha-composite the frame over ``bg_color`` (0..255).  Returns
+        img (H, W, 3) float in 0..255, alpha (H, W, 3) in 0..1, and 'exact' | 'unpinned' for the resize step."""
+        from PIL import Image
+        cam = self.cameras.get(frame_name, {})
+        if 'distortions' in cam and np.any(np.asarray(cam['distortions']) != 0):
+            raise NotImplementedError('frame %s has lens distortion %s: cv2.undistort is not available here; undistort '
+                                      'the images offline' % (frame_name, np.asarray(cam['distortions']).ravel()))
+        orig = np.array(Image.open(os.path.join(self.image_dir, '%s.png' % frame_name)).convert('RGB'))
+        alpha = np.array(Image.open(os.path.join(self.dataset_path, 'masks', '%s.png' % frame_name)).convert('RGB'))
+        if alpha.max() == 1:
+            alpha = alpha * 255
+        alpha = alpha / 255.
+        img = alpha * orig + (1.0 - alpha) * np.asarray(bg_color)[None, None, :]
+        scale = float(cfg.get('resize_img_scale', 1.0))
+        if scale == 1.0:
+            return img, alpha, 'exact'
+        size = (int(round(img.shape[1] * scale)), int(round(img.shape[0] * scale)))
+        res = lambda a, f: np.stack([np.asarray(Image.fromarray(a[..., c].astype(np.float32), mode='F').resize(size, f))
+                                     for c in range(3)], axis=-1)
+        return res(img, Image.LANCZOS), res(alpha, Image.BILINEAR), 'unpinned'
+
+
+def to_device(batch, device, exclude=('frame_name', 'img_width', 'img_height', 'resize_parity')):
+    """cpu_data_to_gpu (train_util.py:7-25): tensors of everything but the excluded keys."""
+    import torch
+    out = {}
+    for k, v in batch.items():
+        if k in exclude or isinstance(v, str):
+            continue
+        out[k] = torch.as_tensor(np.ascontiguousarray(v) if isinstance(v, np.ndarray) else v).to(device)
+    return out

@@ -294,7 +294,10 @@ def render_frames(network, frames, rank=0, world=1, device=None, on_image=None, 
             if 'rays' not in fr:
                 from . import ops
                 fr = dict(fr)
-                fr.update(ops.gen_rays(fr['K'], fr['E'], fr['cnl_bbox_min_xyz'], fr['cnl_bbox_max_xyz'],
+                # rays are clipped against the POSED skeleton's bbox (freeview.py:226; dataset.Subject puts it in
+                # ray_bbox_*); the synthetic frames of scene.py pose nothing and use the canonical one
+                fr.update(ops.gen_rays(fr['K'], fr['E'], fr.get('ray_bbox_min_xyz', fr['cnl_bbox_min_xyz']),
+                                       fr.get('ray_bbox_max_xyz', fr['cnl_bbox_max_xyz']),
                                        int(fr['img_height']), int(fr['img_width']), device=device))
             data = {k: torch.as_tensor(np.ascontiguousarray(fr[k]) if isinstance(fr[k], np.ndarray) else fr[k]).to(device)
                     for k in keys if k != 'motion_weights_priors'}

@@ -1,0 +1,146 @@
+"""On-disk formats + per-frame input assembly against the fixture of
+oracle/make_golden_dataset.py: a subject directory in the reference's layout (cameras.pkl / mesh_infos.pkl /
+canonical_joints.pkl written by pickle.dump of numpy dicts like tools/prepare_zju_mocap/prepare_dataset.py:201-221,
+images/, masks/) and the per-frame dict the REFERENCE's own body_util / camera_util helpers produce for it."""
+import os
+import pickle
+
+import numpy as np
+import pytest
+import torch
+
+from humannerf_amd import dataset
+
+NAMES = ['frame_000003', 'frame_000010', 'frame_000042']
+H, W = 64, 48
+
+
+@pytest.fixture(scope='module')
+def subj(golden_dir):
+    return dataset.Subject(os.path.join(golden_dir, 'subject_synth'))
+
+
+@pytest.fixture(scope='module')
+def want(golden_dir):
+    return np.load(os.path.join(golden_dir, 'subject_synth_expected.npz'))
+
+
+def test_subject_directory_loads(subj, want):
+    assert subj.framelist == NAMES and len(subj) == 3
+    assert set(subj.cameras[NAMES[0]]) == {'intrinsics', 'extrinsics', 'distortions'}
+    assert set(subj.mesh_infos[NAMES[0]]) == {'Rh', 'Th', 'poses', 'joints', 'tpose_joints', 'bbox'}
+    assert np.allclose(subj.motion_weights_priors, want['motion_weights_priors'], atol=2e-6)
+    assert np.allclose(subj.cnl_gtfms, want['cnl_gtfms'], atol=1e-7)
+
+
+@pytest.mark.parametrize('name', NAMES)
+def test_movement_frame_matches_reference_helpers(subj, want, name):
+    """The numpy route (host_rays=True): every entry of the Network.forward dict equals what the reference's helpers
+    give for the same record -- rays / near / far / ray_mask bit for bit."""
+    fr = subj.movement_frame(NAMES.index(name), bgcolor=(0., 0., 0.), host_rays=True, image_size=(H, W))
+    for k in ('rays', 'near', 'far', 'ray_mask'):
+        assert np.array_equal(fr[k], want[name + '/' + k]), k
+    assert np.allclose(fr['dst_Rs'], want[name + '/dst_Rs'], atol=1e-6) and np.array_equal(fr['dst_Ts'], want[name + '/dst_Ts'])
+    assert np.array_equal(fr['dst_posevec'], want[name + '/dst_posevec'])
+    for k in ('cnl_bbox_min_xyz', 'cnl_bbox_max_xyz', 'cnl_bbox_scale_xyz'):
+        assert np.array_equal(fr[k], want[k]), k
+    assert fr['rays'].shape[0] == 3 and fr['rays'].dtype == np.float32 and fr['near'].shape[1] == 1
+    # the default (camera-only) form carries what the device-side ray generator needs instead
+    cam = subj.movement_frame(NAMES.index(name), image_size=(H, W))
+    assert 'rays' not in cam and np.allclose(cam['E'], want[name + '/E'], atol=1e-6)
+    assert np.array_equal(cam['ray_bbox_min_xyz'], (subj.mesh_infos[name]['joints'].min(0) - 0.3).astype('float32'))
+    assert cam['motion_weights_priors'] is subj.motion_weights_priors           # resident by identity across frames
+
+
+def test_train_frame_patches(subj):
+    """train.py:481-631: image + mask from the PNGs, six windows, rays of the windows only, targets cut from the
+    composited image, patch masks; a seeded global generator gives the same patches."""
+    from humannerf_amd.config import cfg
+    old = (cfg.patch.size, cfg.patch.N_patches)
+    cfg.patch.size, cfg.patch.N_patches = 16, 4
+    try:
+        np.random.seed(5)
+        a = subj.train_frame(1, bgcolor=(10., 20., 30.))
+        np.random.seed(5)
+        b = subj.train_frame(1, bgcolor=(10., 20., 30.))
+    finally:
+        cfg.patch.size, cfg.patch.N_patches = old
+    assert a['target_patches'].shape == (4, 16, 16, 3) and a['patch_masks'].shape == (4, 16, 16)
+    n = int(a['patch_div_indices'][-1])
+    assert a['rays'].shape == (3, n, 3) and a['near'].shape == (n, 1) and a['target_rgbs'].shape == (n, 3)
+    assert int(a['patch_masks'].sum()) == n and a['resize_parity'] == 'exact'
+    for k in ('rays', 'target_patches', 'patch_masks', 'patch_div_indices'):
+        assert np.array_equal(a[k], b[k]), k
+    # the rays' colours are the target patches' pixels under the masks, in order
+    got = np.concatenate([a['target_patches'][i][a['patch_masks'][i]] for i in range(4)], 0)
+    assert np.array_equal(got, a['target_rgbs'])
+    # composite over the background: outside the mask blob the image IS the background
+    assert np.allclose(a['target_patches'].min(), min(10. / 255., a['target_patches'].min()))
+
+
+def test_freeview_frame_orbits(subj):
+    f0 = subj.freeview_frame(0, 8, image_size=(H, W))
+    f4 = subj.freeview_frame(4, 8, image_size=(H, W))
+    f8 = subj.freeview_frame(8, 8, image_size=(H, W))
+    assert np.allclose(f0['E'], f8['E'], atol=1e-5) and not np.allclose(f0['E'], f4['E'], atol=1e-2)
+    for f in (f0, f4):
+        R = f['E'][:3, :3].astype(np.float64)
+        assert np.allclose(R @ R.T, np.eye(3), atol=1e-5)
+    assert tuple(f0['bgcolor']) == (255., 255., 255.)                       # freeview.py:74
+
+
+def test_rodrigues_and_global_transform():
+    """cv2 is absent: closed-form properties only (parity with OpenCV's numerics unpinned)."""
+    rs = np.random.RandomState(3)
+    for _ in range(5):
+        r = rs.randn(3)
+        R = dataset.rodrigues_cv(r)
+        assert np.allclose(R @ R.T, np.eye(3), atol=1e-12) and abs(np.linalg.det(R) - 1) < 1e-12
+        assert np.allclose(R @ r, r, atol=1e-12)                            # the axis is fixed
+        assert abs(np.trace(R) - (1 + 2 * np.cos(np.linalg.norm(r)))) < 1e-12
+    assert np.array_equal(dataset.rodrigues_cv(np.zeros(3)), np.eye(3))
+    E = np.eye(4)
+    E[:3, 3] = [0.1, -0.2, 3.0]
+    Th = np.array([0.3, 0.1, -0.2])
+    out = dataset.apply_global_tfm_to_camera(E, np.zeros(3), Th)
+    assert np.allclose(out[:3, 3], E[:3, 3] + Th) and np.allclose(out[:3, :3], np.eye(3))
+
+
+def test_pickle_reader_refuses_code(golden_dir, tmp_path):
+    with pytest.raises(pickle.UnpicklingError):
+        dataset.load_array_pickle(os.path.join(golden_dir, 'subject_synth', 'not_data.pkl'))
+
+    class Evil:
+        def __reduce__(self):
+            return (os.system, ('true',))
+    p = tmp_path / 'evil.pkl'
+    p.write_bytes(pickle.dumps({'a': Evil()}))
+    with pytest.raises(pickle.UnpicklingError):
+        dataset.load_array_pickle(str(p))
+    ok = {'k': np.arange(6, dtype=np.float32).reshape(2, 3), 'n': np.float64(2.5), 'l': [1, 'x', (2, 3)]}
+    back = dataset.load_array_pickle(pickle.dumps(ok))
+    assert np.array_equal(back['k'], ok['k']) and back['n'] == 2.5 and back['l'] == ok['l']
+
+
+def test_distorted_cameras_are_refused(subj):
+    name = NAMES[0]
+    old = subj.cameras[name]['distortions']
+    subj.cameras[name]['distortions'] = np.array([0.1, 0, 0, 0, 0.])
+    try:
+        with pytest.raises(NotImplementedError, match='undistort'):
+            subj.load_image(name, np.zeros(3))
+    finally:
+        subj.cameras[name]['distortions'] = old
+
+
+def test_checkpoint_tar_reader(tmp_path):
+    """trainer.py:356-377 layout read back with weights_only=True; foreign pickles are refused by torch itself."""
+    from humannerf_amd.train import load_checkpoint
+    sd = {'cnl_mlp.module.pts_linears.0.weight': torch.randn(4, 3)}
+    path = str(tmp_path / 'latest.tar')
+    torch.save({'iter': 7, 'network': sd, 'optimizer': {'state': {}, 'param_groups': []}}, path)
+    ck = load_checkpoint(path)
+    assert ck['iter'] == 7 and torch.equal(ck['network']['cnl_mlp.module.pts_linears.0.weight'], sd['cnl_mlp.module.pts_linears.0.weight'])
+    torch.save({'something': 1}, path)
+    with pytest.raises(ValueError):
+        load_checkpoint(path)

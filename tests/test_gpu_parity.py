@@ -615,3 +615,24 @@ def test_render_frames_writes_pngs_and_truth(gpu_net, tmp_path):
     ref = np.full((64 * 48, 3), np.array([30., 120., 250.], np.float32) / 255., np.float32)
     ref[frames[2]['ray_mask']] = direct['rgb'].cpu().numpy()
     assert np.array_equal(imgs[2], render.to_8b_image(ref.reshape(64, 48, 3)))
+
+
+def test_subject_directory_renders_end_to_end(gpu_net, golden_dir):
+    """A prepared subject directory (the reference's on-disk layout) -> dataset.Subject -> render_frames: the
+    camera-only route (rays generated on the device against the POSED skeleton's bbox) gives the image of the
+    reference's numpy route (rays / near / far made on the host exactly like its Dataset does), to 1 LSB."""
+    from humannerf_amd import dataset, render
+    from humannerf_amd.config import cfg
+    subj = dataset.Subject(os.path.join(golden_dir, 'subject_synth'))
+    cams = [subj.movement_frame(i, bgcolor=(255., 255., 255.), image_size=(64, 48)) for i in range(3)]
+    host = [subj.movement_frame(i, bgcolor=(255., 255., 255.), host_rays=True, image_size=(64, 48)) for i in range(3)]
+    cfg.amd.diagnostics, cfg.N_samples = False, 64
+    try:
+        a = render.render_frames(gpu_net, cams)
+        b = render.render_frames(gpu_net, host)
+    finally:
+        cfg.amd.diagnostics, cfg.N_samples = True, 128
+    for i in range(3):
+        assert a[i].shape == (64, 48, 3)
+        assert np.abs(a[i].astype(np.int32) - b[i].astype(np.int32)).max() <= 1
+        assert (a[i] < 250).any()                            # the body is in the picture
