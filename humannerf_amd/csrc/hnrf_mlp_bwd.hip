@@ -420,6 +420,213 @@ static bool dw_plan(int64_t P, int n_out, int n_in, DwPlan& pl, bool f16 = false
 }
 
 
+// ---------------------------------------------------------------------------- dW from half-precision operands
+// Training with cfg.amd.train_dw_mode = 'f16' stores the two operands of every weight gradient -- the activations
+// (training forward) and dZ (backward chain, in its power-of-two scaled domain) -- as f16: half the HBM bytes of the
+// step's largest buffers, written once and read once.  dW = sum over ~10^5..10^6 samples of dZ[s][o] X[s][i] with
+// each operand rounded to 11 bits (round to nearest, unbiased): the rounding errors of different samples are
+// independent, so the relative error of the SUM falls with 1/sqrt(samples) (measured against fp64 by
+// tests/test_gpu_grad.py).  Accumulation stays fp32.
+//
+// Both matrices are row-major [sample][column] and the MFMA contracts over samples, i.e. both operands want 8
+// consecutive SAMPLES of one column per lane.  gfx950 has the instruction for exactly that: rows travel HBM ->
+// registers -> LDS as they are (16-byte chunks, fully coalesced) and ds_read_b64_tr_b16 hands every lane 4 rows of its
+// own column -- a transposed read, no gather loads, no VALU.  LDS image: 32-sample stages, 128-column blocks of 256-byte
+// rows, 16-byte chunk index XORed with (row & 3) << 2 so that the 4 rows of a transposed read fall into 4 different
+// bank quarters (64 columns: 128-byte rows, XOR ((row >> 1) & 1) << 2).  One workgroup per CU owns the whole
+// output like the kernels above; two stages of global loads are in flight per thread (64 KiB per CU).
+typedef _Float16 h16x4 __attribute__((ext_vector_type(4)));
+typedef short vs16x4 __attribute__((__vector_size__(4 * sizeof(short))));
+typedef __attribute__((address_space(3))) vs16x4 lds_vs16x4;
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+template <int C>
+__device__ __forceinline__ int dwh_off(int row, int col) {          // byte offset of (row, col) in a 32 x C stage image
+    if (C >= 128) {
+        const int c = col & 127;
+        return (col >> 7) * (32 * 256) + row * 256 + 16 * ((c >> 3) ^ ((row & 3) << 2)) + 2 * (c & 7);
+    }
+    return row * 128 + 16 * ((col >> 3) ^ (((row >> 1) & 1) << 2)) + 2 * (col & 7);
+}
+
+// 8 consecutive samples (rows kr + 8 h .. + 7 of the stage) of column f0 + (lane & 31): one MFMA A / B operand
+__device__ __forceinline__ h16x8 dwh_frag(unsigned lds_addr, int rowbytes_times_4) {
+    const vs16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_vs16x4*)(size_t)lds_addr);
+    const vs16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_vs16x4*)(size_t)(lds_addr + rowbytes_times_4));
+    union { vs16x4 v[2]; h16x8 h; } u;
+    u.v[0] = lo;
+    u.v[1] = hi;
+    return u.h;
+}
+
+// OT: 32-row tiles of dZ columns per wave (n_out = 128 OT); IT: 32-column tiles of X (n_in padded to 32 IT: 2, 4, 8)
+template <int OT, int IT>
+__global__ __launch_bounds__(256) void mlp_dwh_kernel(const _Float16* __restrict__ dZ, int64_t ldz,
+                                                      const _Float16* __restrict__ X, int64_t ldx, int64_t P,
+                                                      int64_t per_wg, const float* __restrict__ dz_scale,
+                                                      float* __restrict__ part, float* __restrict__ dbpart) {
+    constexpr int NOW = 128 * OT, NIP = 32 * IT;
+    constexpr int ZB = 32 * NOW * 2, XB = 32 * NIP * 2;          // bytes per stage
+    constexpr int ZC = NOW / 64, XC = NIP / 64;                   // 16-byte chunks per thread and stage
+    constexpr int ZROW = NOW >= 128 ? 256 : 128, XROW = NIP >= 128 ? 256 : 128;
+    __shared__ __attribute__((aligned(16))) char lds[2][ZB + XB];
+    const unsigned lbase = (unsigned)(size_t)(__attribute__((address_space(3))) char*)&lds[0][0];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int64_t s0 = (int64_t)blockIdx.x * per_wg;
+    const int64_t s1 = s0 + per_wg < P ? s0 + per_wg : P;
+
+    f32x16 acc[OT][IT];
+#pragma unroll
+    for (int a = 0; a < OT; ++a)
+#pragma unroll
+        for (int b = 0; b < IT; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+    float bsum[OT];
+#pragma unroll
+    for (int a = 0; a < OT; ++a) bsum[a] = 0.f;
+
+    // transposed-read addresses of this lane (row part (kr + 4 j) * rowbytes and the 128-column block are immediates)
+    const int g = lane >> 4, pq = lane & 15, q = pq >> 2, pp = pq & 3;
+    int aoff[OT], boff[IT < 4 ? IT : 4];
+#pragma unroll
+    for (int a = 0; a < OT; ++a) aoff[a] = dwh_off<NOW>(8 * (g >> 1) + q, (32 * OT * w + 32 * a) + 16 * (g & 1) + 4 * pp);
+#pragma unroll
+    for (int b = 0; b < (IT < 4 ? IT : 4); ++b) boff[b] = ZB + dwh_off<NIP>(8 * (g >> 1) + q, 32 * b + 16 * (g & 1) + 4 * pp);
+
+    u32x4 rz[2][ZC], rx[2][XC];
+    auto fetch = [&](int slot, int64_t stage) {
+        const int64_t sb = s0 + 32 * stage;
+#pragma unroll
+        for (int i = 0; i < ZC; ++i) {
+            const int id = tid + 256 * i, row = id / (NOW / 8), ch = id % (NOW / 8);
+            rz[slot][i] = sb + row < s1 ? *reinterpret_cast<const u32x4*>(dZ + (sb + row) * ldz + 8 * ch) : u32x4{0u, 0u, 0u, 0u};
+        }
+#pragma unroll
+        for (int i = 0; i < XC; ++i) {
+            const int id = tid + 256 * i, row = id / (NIP / 8), ch = id % (NIP / 8);
+            rx[slot][i] = sb + row < s1 ? *reinterpret_cast<const u32x4*>(X + (sb + row) * ldx + 8 * ch) : u32x4{0u, 0u, 0u, 0u};
+        }
+    };
+    auto stage_in = [&](int slot, int buf) {
+#pragma unroll
+        for (int i = 0; i < ZC; ++i) {
+            const int id = tid + 256 * i, row = id / (NOW / 8), ch = id % (NOW / 8);
+            *reinterpret_cast<u32x4*>(&lds[buf][dwh_off<NOW>(row, 8 * ch)]) = rz[slot][i];
+        }
+#pragma unroll
+        for (int i = 0; i < XC; ++i) {
+            const int id = tid + 256 * i, row = id / (NIP / 8), ch = id % (NIP / 8);
+            *reinterpret_cast<u32x4*>(&lds[buf][ZB + dwh_off<NIP>(row, 8 * ch)]) = rx[slot][i];
+        }
+    };
+    auto compute = [&](int buf) {
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            h16x8 af[OT];
+#pragma unroll
+            for (int a = 0; a < OT; ++a) {
+                af[a] = dwh_frag(lbase + buf * (ZB + XB) + aoff[a] + 16 * ks * ZROW, 4 * ZROW);
+#pragma unroll
+                for (int j = 0; j < 8; j += 2)
+                    bsum[a] = __builtin_amdgcn_fdot2(h16x2{af[a][j], af[a][j + 1]}, h16x2{(_Float16)1.0f, (_Float16)1.0f}, bsum[a], false);
+            }
+#pragma unroll
+            for (int it = 0; it < IT; ++it) {
+                const h16x8 bf = dwh_frag(lbase + buf * (ZB + XB) + boff[it & 3] + (it >> 2) * (32 * 256) + 16 * ks * XROW, 4 * XROW);
+#pragma unroll
+                for (int a = 0; a < OT; ++a) acc[a][it] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[a], bf, acc[a][it], 0, 0, 0);
+            }
+        }
+    };
+
+    const int64_t ns = per_wg / 32;                                // per_wg is a multiple of 64
+    fetch(0, 0);
+    fetch(1, 1);
+    stage_in(0, 0);
+    __syncthreads();
+    for (int64_t s = 0; s < ns; s += 2) {
+        fetch(0, s + 2);                 // slot 0 (stage s) already sits in LDS buffer 0
+        compute(0);
+        stage_in(1, 1);                  // stage s + 1 -> buffer 1 (last read before the previous barrier)
+        __syncthreads();
+        fetch(1, s + 3);
+        compute(1);
+        stage_in(0, 0);                  // stage s + 2 -> buffer 0
+        __syncthreads();
+    }
+
+    const float inv = dz_scale ? 1.0f / dz_scale[0] : 1.0f;
+    const int c = lane & 31, h = lane >> 5;
+    float* out = part + (int64_t)blockIdx.x * NOW * NIP;
+#pragma unroll
+    for (int a = 0; a < OT; ++a)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int o = 32 * OT * w + 32 * a + (r & 3) + 8 * (r >> 2) + 4 * h;
+#pragma unroll
+            for (int it = 0; it < IT; ++it) out[(int64_t)o * NIP + 32 * it + c] = acc[a][it][r] * inv;
+        }
+    if (dbpart != nullptr) {
+#pragma unroll
+        for (int a = 0; a < OT; ++a) {
+            const float t = bsum[a] + __shfl_xor(bsum[a], 32, 64);
+            if (h == 0) dbpart[(int64_t)blockIdx.x * NOW + 32 * OT * w + 32 * a + c] = t * inv;
+        }
+    }
+}
+
+// head layers with f16 activations: mlp_dw_head_kernel reading X as halves
+template <int NI>
+__global__ __launch_bounds__(NI) void mlp_dwh_head_kernel(const float* __restrict__ dY, int64_t ldy, int n_out,
+                                                           const _Float16* __restrict__ X, int64_t ldx, int64_t P,
+                                                           int64_t per_wg, float* __restrict__ part,
+                                                           float* __restrict__ dbpart) {
+    const int i = threadIdx.x;
+    const int64_t s0 = (int64_t)blockIdx.x * per_wg;
+    const int64_t s1 = s0 + per_wg < P ? s0 + per_wg : P;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f, b = 0.f;
+    const _Float16* xp = X + i;
+    auto step = [&](int64_t s, float x) {
+        const float* g = dY + s * ldy;
+        const float g0 = g[0], g1 = n_out > 1 ? g[1] : 0.f, g2 = n_out > 2 ? g[2] : 0.f, g3 = n_out > 3 ? g[3] : 0.f;
+        a0 = fmaf(g0, x, a0);
+        a1 = fmaf(g1, x, a1);
+        a2 = fmaf(g2, x, a2);
+        a3 = fmaf(g3, x, a3);
+        b += i == 0 ? g0 : (i == 1 ? g1 : (i == 2 ? g2 : g3));
+    };
+    int64_t s = s0;
+    for (; s + 8 <= s1; s += 8) {
+        float x[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) x[u] = (float)xp[(s + u) * ldx];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) step(s + u, x[u]);
+    }
+    for (; s < s1; ++s) step(s, (float)xp[s * ldx]);
+    float* out = part + (int64_t)blockIdx.x * 4 * NI;
+    out[i] = a0;
+    out[NI + i] = a1;
+    out[2 * NI + i] = a2;
+    out[3 * NI + i] = a3;
+    if (dbpart != nullptr && i < 4) dbpart[(int64_t)blockIdx.x * 4 + i] = b;
+}
+
+static bool dwh_plan(int64_t P, int n_out, int n_in, DwPlan& pl) {
+    if (n_out == 256 || n_out == 128) pl.now = n_out; else if (n_out >= 1 && n_out <= 4) pl.now = 4; else return false;
+    if (n_in == 256 || n_in == 128) pl.nip = n_in;
+    else if (n_in >= 1 && n_in <= 64 && n_out > 4) pl.nip = 64;
+    else return false;
+    int64_t per = (P + DW_SPLIT - 1) / DW_SPLIT;
+    per = (per + 63) / 64 * 64;
+    if (per < 128) per = 128;
+    if (pl.now == 4 && per > 512) per = 512;
+    pl.per_wg = per;
+    pl.nsplit = (int)((P + per - 1) / per);
+    return true;
+}
+
 // =========================================================================== dX chain
 // Backward through all layers of one MLP for 32 samples per wave, register-resident like the
 // forward (hnrf_mlp.hip): dH_{l-1}^T [in-features x samples] = W_l^T . dZ_l^T, then
@@ -772,6 +979,54 @@ extern "C" int hnrf_mlp_dw(const float* dZ, int64_t ldz, const float* X, int64_t
     hipLaunchKernelGGL(mlp_dw_reduce_kernel, dim3(nblk), dim3(256), 0, st, part, dbpart, pl.nsplit, pl.now,
                        pl.nip, n_out, n_in, dW, ldw, db);
     return check_launch("hnrf_mlp_dw (reduce)");
+}
+
+extern "C" size_t hnrf_mlp_dw_h_workspace_bytes(int64_t P, int n_out, int n_in) {
+    DwPlan pl;
+    if (P <= 0 || !dwh_plan(P, n_out, n_in, pl)) return 0;
+    return ((size_t)pl.nsplit * pl.now * pl.nip + (size_t)pl.nsplit * pl.now) * sizeof(float);
+}
+
+extern "C" int hnrf_mlp_dw_h(const void* dZ, int64_t ldz, const void* X, int64_t ldx, int64_t P, int n_out, int n_in,
+                             const float* dz_scale, float* dW, int64_t ldw, float* db, void* workspace,
+                             size_t workspace_bytes, void* stream) {
+    HNRF_REQUIRE(dZ && X && dW && workspace, HNRF_E_ARG, "hnrf_mlp_dw_h: null pointer");
+    DwPlan pl;
+    HNRF_REQUIRE(P > 0 && dwh_plan(P, n_out, n_in, pl), HNRF_E_UNSUPPORTED,
+                 "hnrf_mlp_dw_h: shape P=%lld n_out=%d n_in=%d not built (n_out 128|256 with n_in 128|256|<=64; n_out <= 4 "
+                 "with n_in 128|256)", (long long)P, n_out, n_in);
+    HNRF_REQUIRE(workspace_bytes >= hnrf_mlp_dw_h_workspace_bytes(P, n_out, n_in), HNRF_E_ARG,
+                 "hnrf_mlp_dw_h: workspace too small");
+    float* part = (float*)workspace;
+    float* dbpart = part + (size_t)pl.nsplit * pl.now * pl.nip;
+    hipStream_t st = (hipStream_t)stream;
+    if (n_out <= 4) {
+        // dZ is the fp32 [P, n_out] gradient at the head's output; X the f16 activations of the last hidden layer
+        HNRF_REQUIRE(ldz >= n_out && ldx >= n_in && ldw >= n_in, HNRF_E_ARG, "hnrf_mlp_dw_h: row stride below width");
+        if (n_in == 256)
+            hipLaunchKernelGGL(mlp_dwh_head_kernel<256>, dim3(pl.nsplit), dim3(256), 0, st, (const float*)dZ, ldz, n_out,
+                               (const _Float16*)X, ldx, P, pl.per_wg, part, db ? dbpart : nullptr);
+        else
+            hipLaunchKernelGGL(mlp_dwh_head_kernel<128>, dim3(pl.nsplit), dim3(128), 0, st, (const float*)dZ, ldz, n_out,
+                               (const _Float16*)X, ldx, P, pl.per_wg, part, db ? dbpart : nullptr);
+    } else {
+        HNRF_REQUIRE(ldz >= pl.now && ldx >= pl.nip && ldw >= n_in, HNRF_E_ARG,
+                     "hnrf_mlp_dw_h: row stride below the padded width (X rows must hold %d halves)", pl.nip);
+        HNRF_REQUIRE((((uintptr_t)dZ | (uintptr_t)X) & 15) == 0 && ldz % 8 == 0 && ldx % 8 == 0, HNRF_E_ARG,
+                     "hnrf_mlp_dw_h: dZ and X must be 16-byte aligned with row strides that are multiples of 8 halves");
+#define HNRF_DWH(OT, IT)                                                                                            \
+    hipLaunchKernelGGL((mlp_dwh_kernel<OT, IT>), dim3(pl.nsplit), dim3(256), 0, st, (const _Float16*)dZ, ldz,       \
+                       (const _Float16*)X, ldx, P, pl.per_wg, dz_scale, part, db ? dbpart : nullptr)
+        if (n_out == 256) { if (pl.nip == 256) HNRF_DWH(2, 8); else if (pl.nip == 128) HNRF_DWH(2, 4); else HNRF_DWH(2, 2); }
+        else { if (pl.nip == 256) HNRF_DWH(1, 8); else if (pl.nip == 128) HNRF_DWH(1, 4); else HNRF_DWH(1, 2); }
+#undef HNRF_DWH
+    }
+    int rc = check_launch("hnrf_mlp_dw_h");
+    if (rc) return rc;
+    const int nblk = pl.now * pl.nip / 64 + (db ? (pl.now + 63) / 64 : 0);
+    hipLaunchKernelGGL(mlp_dw_reduce_kernel, dim3(nblk), dim3(256), 0, st, part, dbpart, pl.nsplit, pl.now,
+                       pl.nip, n_out, n_in, dW, ldw, db);
+    return check_launch("hnrf_mlp_dw_h (reduce)");
 }
 
 extern "C" size_t hnrf_canonical_bwd_packed_bytes(int mode) {

@@ -360,6 +360,33 @@ def mlp_dw(dZ, X, dW_out=None, want_db=True, mode='f32', dz_amax=None):
     return dW_out, db
 
 
+def mlp_dw_h(dZ, X, dW_out=None, want_db=True, dz_scale=None, n_in=None):
+    """hnrf_mlp_dw_h: dW = dZ^T X / scale (and db) from f16 operands.  dZ [P, n_out] f16 (n_out 128 | 256) or, for a
+    head, fp32 [P, n_out <= 4]; X [P, >= n_in] f16 whose rows are zero-padded to 64 / 128 / 256 columns; ``n_in``:
+    columns of dW (default X.shape[1]); dz_scale: device scalar the stored dZ was multiplied by."""
+    lib = _lib.load()
+    head = dZ.shape[1] <= 4
+    assert X.dtype == torch.float16 and dZ.dtype == (torch.float32 if head else torch.float16) and dZ.is_cuda and X.is_cuda
+    assert dZ.dim() == 2 and X.dim() == 2 and dZ.stride(1) == 1 and X.stride(1) == 1 and dZ.shape[0] == X.shape[0]
+    P, n_out = dZ.shape
+    n_in = int(X.shape[1] if n_in is None else n_in)
+    if dW_out is None:
+        dW_out = torch.empty(n_out, n_in, device=dZ.device)
+    assert dW_out.stride(1) == 1 and dW_out.shape[0] == n_out and dW_out.shape[1] == n_in and dW_out.dtype == torch.float32
+    db = torch.empty(n_out, device=dZ.device) if want_db else None
+    need = lib.hnrf_mlp_dw_h_workspace_bytes(P, n_out, n_in)
+    if need == 0:
+        raise _lib.HnrfError('hnrf_mlp_dw_h: shape (%d, %d, %d) not built' % (P, n_out, n_in))
+    key = dZ.device.index
+    ws = _dw_ws.get(key)
+    if ws is None or ws.numel() < need:
+        ws = _dw_ws[key] = torch.empty(need, dtype=torch.uint8, device=dZ.device)
+    _lib.check(lib.hnrf_mlp_dw_h(dZ.data_ptr(), dZ.stride(0), X.data_ptr(), X.stride(0), P, n_out, n_in, _ptr(dz_scale),
+                                 dW_out.data_ptr(), dW_out.stride(0), _ptr(db), ws.data_ptr(), ws.numel(), _stream()),
+               'hnrf_mlp_dw_h')
+    return dW_out, db
+
+
 def sample_warp_bwd(rays_o, rays_d, z_vals, motion_Rs, motion_Ts, vol, bbox_min, bbox_scale, x_skel, fg_mask,
                     g_x_skel, g_mask):
     """Returns d_vol (same shape as vol; background channel zero), d_Rs (B,3,3), d_Ts (B,3)."""

@@ -220,6 +220,19 @@ int hnrf_mlp_dw(const float* dZ, int64_t ldz, const float* X, int64_t ldx, int64
                 int mode, const float* dz_amax, int n_amax, float* dW, int64_t ldw, float* db, void* workspace,
                 size_t workspace_bytes, void* stream);
 
+/* The same weight / bias gradient from HALF-PRECISION operands (training with the activations and dZ stored as
+ * f16: half the HBM traffic of the step's two largest buffers).  dZ [P, ldz] and X [P, ldx] are row-major f16
+ * (16-byte aligned, strides multiples of 8 halves, X rows padded with zeros to 64 / 128 / 256 columns); dZ may carry a
+ * power-of-two scale: dz_scale (nullable device scalar) is divided out of dW and db.  One f16 MFMA per product,
+ * fp32 accumulation over the samples; both operands reach the matrix pipe through gfx950's transposed LDS read
+ * (ds_read_b64_tr_b16).  Each operand is rounded to 11 bits, unbiased: the relative error of a sum over N samples is
+ * ~2^-12 / sqrt(N).  n_out <= 4 (heads): dZ is the fp32 [P, n_out] gradient at the head output, X the f16 activations.
+ * Same shapes, workspace rules and determinism as hnrf_mlp_dw. */
+size_t hnrf_mlp_dw_h_workspace_bytes(int64_t P, int n_out, int n_in);
+int hnrf_mlp_dw_h(const void* dZ, int64_t ldz, const void* X, int64_t ldx, int64_t P, int n_out, int n_in,
+                  const float* dz_scale, float* dW, int64_t ldw, float* db, void* workspace, size_t workspace_bytes,
+                  void* stream);
+
 /* Backward through all layers of one MLP (the dX chain of autograd over mlp_rgb_sigma.py / mlp_offset.py),
  * register-resident like the forward, with the backward of the positional encoding fused.
  *  *_bwd_pack: transposed weight image from the same nn.Linear weights hnrf_*_pack takes (re-pack after
