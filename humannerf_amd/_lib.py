@@ -35,7 +35,7 @@ SIGNATURES = {
     'hnrf_mlp_dw_workspace_bytes': (_sz, [_i64, _int, _int]),
     'hnrf_mlp_dw': (_int, [_vp, _i64, _vp, _i64, _i64, _int, _int, _int, _vp, _int, _vp, _i64, _vp, _vp, _sz, _vp]),
     'hnrf_mlp_dw_h_workspace_bytes': (_sz, [_i64, _int, _int]),
-    'hnrf_mlp_dw_h': (_int, [_vp, _i64, _vp, _i64, _i64, _int, _int, _vp, _vp, _i64, _vp, _vp, _sz, _vp]),
+    'hnrf_mlp_dw_h': (_int, [_vp, _i64, _vp, _i64, _i64, _int, _int, _int, _vp, _vp, _i64, _vp, _vp, _sz, _vp]),
     'hnrf_canonical_bwd_packed_bytes': (_sz, [_int]),
     'hnrf_nonrigid_bwd_packed_bytes': (_sz, [_int]),
     'hnrf_canonical_bwd_pack': (_int, [_vp, _int, _vp, _vp]),

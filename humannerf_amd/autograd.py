@@ -39,6 +39,39 @@ def _weight_grads(dZ, acts, pe, dY, weights, skip_layer, skip_order, amax=None, 
     return gW, gb
 
 
+def _weight_grads_h(dZ, scale, acts, pe, dY, weights, skip_layer, skip_order, npe):
+    """The same from f16 operands (cfg.amd.train_operands = 'f16'): dZ [L][P128][W] f16 in the chain's scaled domain
+    with ``scale`` [L], acts f16 -- both in the blocked layout the training kernels write -- pe row-major f16 [P][64]
+    (``npe`` real columns), dY fp32 [P, 3|4] at the head output.  Every layer runs on hnrf_mlp_dw_h (transposed LDS reads,
+    one f16 MFMA per product, fp32 accumulation)."""
+    n_hidden = acts.shape[0]
+    P = dY.shape[0]
+    gW, gb = [None] * (n_hidden + 1), [None] * (n_hidden + 1)
+    gW[n_hidden], gb[n_hidden] = ops.mlp_dw_h(dY, acts[n_hidden - 1], P=P, x_blocked=True)
+    for l in range(n_hidden):
+        sc = scale[l:l + 1]
+        if l == 0:
+            gW[l], gb[l] = ops.mlp_dw_h(dZ[l], pe, dz_scale=sc, n_in=npe, P=P, z_blocked=True)
+        elif l == skip_layer:
+            gW[l] = torch.empty_like(weights[l])
+            pe_cols = gW[l][:, :npe] if skip_order == 'pe_first' else gW[l][:, -npe:]
+            h_cols = gW[l][:, npe:] if skip_order == 'pe_first' else gW[l][:, :-npe]
+            ops.mlp_dw_h(dZ[l], pe, pe_cols, want_db=False, dz_scale=sc, n_in=npe, P=P, z_blocked=True)
+            _, gb[l] = ops.mlp_dw_h(dZ[l], acts[l - 1], h_cols, dz_scale=sc, P=P, z_blocked=True, x_blocked=True)
+        else:
+            gW[l], gb[l] = ops.mlp_dw_h(dZ[l], acts[l - 1], dz_scale=sc, P=P, z_blocked=True, x_blocked=True)
+    return gW, gb
+
+
+def training_modes():
+    """(forward, chain, dW) arithmetic of the training kernels and whether the saved operands are f16.
+    cfg.amd.train_operands = 'f16' needs split-f16 arithmetic in the forward and the chain."""
+    fwd, chain, dw = (amd_option('train_mlp_mode', 'f16x3'), amd_option('train_chain_mode', 'f16x3'),
+                      amd_option('train_dw_mode', 'f16x3'))
+    half = amd_option('train_operands', 'f16') == 'f16' and fwd == 'f16x3' and chain == 'f16x3' and dw == 'f16x3'
+    return fwd, chain, dw, half
+
+
 class RenderRays(torch.autograd.Function):
     """rgb, alpha, depth[, 8 diagnostic outputs] = RenderRays.apply(consts..., motion_Rs, motion_Ts, vol, *mlp_params)
 
@@ -56,17 +89,19 @@ class RenderRays(torch.autograd.Function):
         motion_Rs, motion_Ts, vol = motion_Rs.contiguous(), motion_Ts.contiguous(), vol.contiguous()
         z, x_skel, mask, bmw = ops.sample_warp(rays_o, rays_d, near, far, t_rand, motion_Rs, motion_Ts, vol, bbox_min,
                                                bbox_scale, n_samples, want_bmw=bool(diag))
-        mode = amd_option('train_mlp_mode', 'f16x3')
+        mode, _, _, half = training_modes()
+        tmode = 'f16x3h' if half else mode
         if use_nonrigid:
             nr_packed = ops.nonrigid_pack(nr_w, nr_b, cond, mode)
-            xyz, offsets, pe_n, acts_n, bits_n = ops.nonrigid_train(x_skel, hann_w, nr_packed, mode)
+            xyz, offsets, pe_n, acts_n, bits_n = ops.nonrigid_train(x_skel, hann_w, nr_packed, tmode)
         else:
             xyz, pe_n, acts_n, bits_n = x_skel, None, None, None
             offsets = torch.zeros_like(x_skel) if diag else None            # network.py:276-277
         cn_packed = ops.canonical_pack(cn_w, cn_b, mode)
-        raw, pe_c, acts_c, bits_c = ops.canonical_train(xyz, cn_packed, mode)
+        raw, pe_c, acts_c, bits_c = ops.canonical_train(xyz, cn_packed, tmode)
         out = ops.composite(raw, mask, z, rays_d, xyz if diag else None, bg, diagnostics=bool(diag))
         ctx.use_nonrigid = use_nonrigid
+        ctx.half = half
         ctx.n_out = 11 if diag else 3
         ctx.save_for_backward(rays_o, rays_d, z, x_skel, mask, xyz, raw, pe_c, acts_c, pe_n, acts_n, motion_Rs,
                               motion_Ts, vol, bbox_min, bbox_scale, hann_w, cond, bg, bits_c, bits_n, *nr_w, *cn_w)
@@ -88,18 +123,24 @@ class RenderRays(torch.autograd.Function):
         d_raw, d_mask = ops.composite_bwd(raw, mask, z, rays_d, bg, c(g_rgb), c(g_alpha), c(g_depth))
         # canonical MLP (skip layer 5 takes [PE63 | h]): dX chain with the PE backward fused, then the weight gradients
         d_raw = d_raw.view(P, 4)
-        dw_mode = amd_option('train_dw_mode', 'f16x3')
-        dZc, d_xyz, amax_c = ops.canonical_bwd(xyz.reshape(P, 3), d_raw, bits_c, cn_w,
-                                               amd_option('train_chain_mode', 'f16x3'))
-        gWc, gbc = _weight_grads(dZc, acts_c, pe_c, d_raw, cn_w, skip_layer=5, skip_order='pe_first', amax=amax_c,
-                                 mode=dw_mode)
+        _, chain_mode, dw_mode, _ = training_modes()
+        if ctx.half:
+            dZc, d_xyz, sc_c = ops.canonical_bwd(xyz.reshape(P, 3), d_raw, bits_c, cn_w, 'f16x3h')
+            gWc, gbc = _weight_grads_h(dZc, sc_c, acts_c, pe_c, d_raw, cn_w, skip_layer=5, skip_order='pe_first', npe=63)
+        else:
+            dZc, d_xyz, amax_c = ops.canonical_bwd(xyz.reshape(P, 3), d_raw, bits_c, cn_w, chain_mode)
+            gWc, gbc = _weight_grads(dZc, acts_c, pe_c, d_raw, cn_w, skip_layer=5, skip_order='pe_first', amax=amax_c,
+                                     mode=dw_mode)
         del dZc
         if ctx.use_nonrigid:
             # xyz = x_skel + offset; layer 0 input [cond69 | PE36], skip layer 4 takes [h | PE36]
-            dZn, d_x_skel, amax_n = ops.nonrigid_bwd(x_skel.reshape(P, 3), hann_w, d_xyz, bits_n, nr_w,
-                                                     amd_option('train_chain_mode', 'f16x3'))
-            gWn, gbn = _weight_grads(dZn, acts_n, pe_n, d_xyz, nr_w, skip_layer=4, skip_order='h_first', amax=amax_n,
-                                     mode=dw_mode)
+            if ctx.half:
+                dZn, d_x_skel, sc_n = ops.nonrigid_bwd(x_skel.reshape(P, 3), hann_w, d_xyz, bits_n, nr_w, 'f16x3h')
+                gWn, gbn = _weight_grads_h(dZn, sc_n, acts_n, pe_n, d_xyz, nr_w, skip_layer=4, skip_order='h_first', npe=36)
+            else:
+                dZn, d_x_skel, amax_n = ops.nonrigid_bwd(x_skel.reshape(P, 3), hann_w, d_xyz, bits_n, nr_w, chain_mode)
+                gWn, gbn = _weight_grads(dZn, acts_n, pe_n, d_xyz, nr_w, skip_layer=4, skip_order='h_first', amax=amax_n,
+                                         mode=dw_mode)
             # condition-code columns of layer 0: the same vector for every sample
             gWn[0] = torch.cat([gbn[0][:, None] * cond.reshape(1, -1), gWn[0]], dim=1)
         else:

@@ -124,6 +124,11 @@ _DEFAULTS = {
         'train_dw_mode': 'f16x3',
         # arithmetic of the two dX chains ('f32' | 'f16x3')
         'train_chain_mode': 'f16x3',
+        # storage of the weight-gradient operands between the kernels of a training step (with split-f16 arithmetic in
+        # all three places above): 'f16' = activations and dZ travel as f16 (half the HBM bytes of the step's largest
+        # buffers; every product of the weight-gradient sums uses 11-bit operands, fp32 accumulation over >= 10^5
+        # samples), 'f32' = fp32 storage, 22-bit split operands in the weight-gradient kernel
+        'train_operands': 'f16',
         # materialise the per-sample diagnostic outputs the reference always
         # returns (backward_motion_weights, xyz_on_rays, ...; ~17 KB/ray).
         'diagnostics': True,

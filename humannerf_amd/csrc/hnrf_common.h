@@ -51,22 +51,22 @@ int nonrigid16_pack(const float* const* w, const float* const* b, const float* c
 int canonical16_fwd(const float* xyz, const void* packed, int64_t P, float* raw, const int* idx, const int* count,
                     hipStream_t st);
 int canonical16_fwd_train(const float* xyz, const void* packed, int64_t P, float* raw, float* pe_out, float* acts,
-                          uint32_t* relu_bits, hipStream_t st);
+                          uint32_t* relu_bits, int half, hipStream_t st);
 int nonrigid16_fwd(const float* x_skel, const float* hann_w, const void* packed, int64_t P, float* xyz,
                    float* offsets, const int* idx, const int* count, hipStream_t st);
 
 int nonrigid16_fwd_train(const float* x_skel, const float* hann_w, const void* packed, int64_t P, float* xyz,
-                         float* offsets, float* pe_out, float* acts, uint32_t* relu_bits, hipStream_t st);
+                         float* offsets, float* pe_out, float* acts, uint32_t* relu_bits, int half, hipStream_t st);
 
 size_t canonical16_bwd_bytes();
 int canonical16_bwd_pack(const float* const* w, void* packed, hipStream_t st);
 int canonical16_bwd(const float* xyz, const float* d_raw, const uint32_t* relu_bits, const void* packed, int64_t P,
-                    const float* d_raw_amax, float* dZ, float* d_xyz, float* dz_amax, hipStream_t st);
+                    const float* d_raw_amax, float* dZ, float* d_xyz, float* dz_amax, int half, hipStream_t st);
 
 size_t nonrigid16_bwd_bytes();
 int nonrigid16_bwd_pack(const float* const* w, void* packed, hipStream_t st);
 int nonrigid16_bwd(const float* x_skel, const float* hann_w, const float* d_xyz, const uint32_t* relu_bits,
                    const void* packed, int64_t P, const float* d_xyz_amax, float* dZ, float* d_x_skel, float* dz_amax,
-                   hipStream_t st);
+                   int half, hipStream_t st);
 
 }  // namespace hnrf

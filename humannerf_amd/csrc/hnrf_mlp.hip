@@ -470,14 +470,14 @@ extern "C" int hnrf_canonical_fwd_train(const float* xyz, const void* packed, in
                                         float* pe_out, float* acts, uint32_t* relu_bits, void* stream) {
     HNRF_REQUIRE(xyz && packed && raw && pe_out && acts && relu_bits, HNRF_E_ARG,
                  "hnrf_canonical_fwd_train: null pointer");
-    HNRF_REQUIRE(mode == HNRF_MLP_F32 || mode == HNRF_MLP_F16X3, HNRF_E_UNSUPPORTED,
+    HNRF_REQUIRE(mode == HNRF_MLP_F32 || mode == HNRF_MLP_F16X3 || mode == HNRF_MLP_F16X3_H, HNRF_E_UNSUPPORTED,
                  "hnrf_canonical_fwd_train: mode %d not built", mode);
     HNRF_REQUIRE(P >= 0 && (P + 127) / 128 < 2147483647LL, HNRF_E_ARG, "hnrf_canonical_fwd_train: bad P");
     HNRF_REQUIRE((((uintptr_t)packed | (uintptr_t)raw | (uintptr_t)acts) & 15) == 0, HNRF_E_ARG,
                  "hnrf_canonical_fwd_train: packed/raw/acts must be 16-byte aligned");
     if (P == 0) return HNRF_OK;
-    if (mode == HNRF_MLP_F16X3)
-        return canonical16_fwd_train(xyz, packed, P, raw, pe_out, acts, relu_bits, (hipStream_t)stream);
+    if (mode != HNRF_MLP_F32)
+        return canonical16_fwd_train(xyz, packed, P, raw, pe_out, acts, relu_bits, mode == HNRF_MLP_F16X3_H, (hipStream_t)stream);
     hipLaunchKernelGGL(canonical_f32_kernel<true>, dim3((unsigned)((P + 127) / 128)), dim3(256), 0,
                        (hipStream_t)stream, xyz, (const float*)packed, P, (float4*)raw, pe_out, acts, relu_bits, nullptr, nullptr);
     return check_launch("hnrf_canonical_fwd_train");
@@ -512,15 +512,15 @@ extern "C" int hnrf_nonrigid_fwd_train(const float* x_skel, const float* hann_w,
                                        uint32_t* relu_bits, void* stream) {
     HNRF_REQUIRE(x_skel && hann_w && packed && xyz && pe_out && acts && relu_bits, HNRF_E_ARG,
                  "hnrf_nonrigid_fwd_train: null pointer");
-    HNRF_REQUIRE(mode == HNRF_MLP_F32 || mode == HNRF_MLP_F16X3, HNRF_E_UNSUPPORTED,
+    HNRF_REQUIRE(mode == HNRF_MLP_F32 || mode == HNRF_MLP_F16X3 || mode == HNRF_MLP_F16X3_H, HNRF_E_UNSUPPORTED,
                  "hnrf_nonrigid_fwd_train: mode %d not built", mode);
     HNRF_REQUIRE(P >= 0 && (P + 127) / 128 < 2147483647LL, HNRF_E_ARG, "hnrf_nonrigid_fwd_train: bad P");
     HNRF_REQUIRE((((uintptr_t)packed | (uintptr_t)acts) & 15) == 0, HNRF_E_ARG,
                  "hnrf_nonrigid_fwd_train: packed/acts must be 16-byte aligned");
     if (P == 0) return HNRF_OK;
-    if (mode == HNRF_MLP_F16X3)
+    if (mode != HNRF_MLP_F32)
         return nonrigid16_fwd_train(x_skel, hann_w, packed, P, xyz, offsets, pe_out, acts, relu_bits,
-                                    (hipStream_t)stream);
+                                    mode == HNRF_MLP_F16X3_H, (hipStream_t)stream);
     hipLaunchKernelGGL(nonrigid_f32_kernel<true>, dim3((unsigned)((P + 127) / 128)), dim3(256), 0,
                        (hipStream_t)stream, x_skel, hann_w, (const float*)packed, P, xyz, offsets, pe_out, acts, relu_bits, nullptr, nullptr);
     return check_launch("hnrf_nonrigid_fwd_train");

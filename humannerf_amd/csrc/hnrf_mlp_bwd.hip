@@ -450,17 +450,23 @@ __device__ __forceinline__ int dwh_off(int row, int col) {          // byte offs
 }
 
 // 8 consecutive samples (rows kr + 8 h .. + 7 of the stage) of column f0 + (lane & 31): one MFMA A / B operand
-__device__ __forceinline__ h16x8 dwh_frag(unsigned lds_addr, int rowbytes_times_4) {
-    const vs16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_vs16x4*)(size_t)lds_addr);
-    const vs16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_vs16x4*)(size_t)(lds_addr + rowbytes_times_4));
+__device__ __forceinline__ h16x8 dwh_frag2(unsigned addr_lo, unsigned addr_hi) {
+    const vs16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_vs16x4*)(size_t)addr_lo);
+    const vs16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_vs16x4*)(size_t)addr_hi);
     union { vs16x4 v[2]; h16x8 h; } u;
     u.v[0] = lo;
     u.v[1] = hi;
     return u.h;
 }
 
-// OT: 32-row tiles of dZ columns per wave (n_out = 128 OT); IT: 32-column tiles of X (n_in padded to 32 IT: 2, 4, 8)
-template <int OT, int IT>
+// OT: 32-row tiles of dZ columns per wave (n_out = 128 OT); IT: 32-column tiles of X (n_in padded to 32 IT: 2, 4, 8).
+// ZBLK / XBLK: the matrix arrives in the BLOCKED layout the training kernels write (hnrf_mlp_f16.hip, save_pair_bh):
+// 32-sample blocks of [32-feature tile][k = 8 groups of 4 features][32 sample slots][4 halves], sample c in slot
+// c ^ 4 k.  A stage is then ONE contiguous block, copied to LDS as it is (linear 16-byte chunks), and the slot swizzle
+// is what makes the transposed reads conflict-free: a read takes 4 samples x 8 groups per lane half, whose 8-byte
+// granules (k 32 + (c ^ 4 k)) 8 cover the 64 banks once.  Rows past P are zero in a blocked dZ (the chain kernels
+// store zeros there), so padded blocks need no masking.
+template <int OT, int IT, bool ZBLK, bool XBLK>
 __global__ __launch_bounds__(256) void mlp_dwh_kernel(const _Float16* __restrict__ dZ, int64_t ldz,
                                                       const _Float16* __restrict__ X, int64_t ldx, int64_t P,
                                                       int64_t per_wg, const float* __restrict__ dz_scale,
@@ -469,6 +475,7 @@ __global__ __launch_bounds__(256) void mlp_dwh_kernel(const _Float16* __restrict
     constexpr int ZB = 32 * NOW * 2, XB = 32 * NIP * 2;          // bytes per stage
     constexpr int ZC = NOW / 64, XC = NIP / 64;                   // 16-byte chunks per thread and stage
     constexpr int ZROW = NOW >= 128 ? 256 : 128, XROW = NIP >= 128 ? 256 : 128;
+    static_assert(!XBLK || NIP >= 128, "blocked X: hidden layers only");
     __shared__ __attribute__((aligned(16))) char lds[2][ZB + XB];
     const unsigned lbase = (unsigned)(size_t)(__attribute__((address_space(3))) char*)&lds[0][0];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -486,54 +493,79 @@ __global__ __launch_bounds__(256) void mlp_dwh_kernel(const _Float16* __restrict
 #pragma unroll
     for (int a = 0; a < OT; ++a) bsum[a] = 0.f;
 
-    // transposed-read addresses of this lane (row part (kr + 4 j) * rowbytes and the 128-column block are immediates)
+    // transposed-read addresses of this lane.  Row-major image: one per operand tile (the row part (kr + 4 j) rowbytes
+    // and the 128-column block are immediates).  Blocked image: one per (k-step, j) -- the tile is an immediate.
     const int g = lane >> 4, pq = lane & 15, q = pq >> 2, pp = pq & 3;
-    int aoff[OT], boff[IT < 4 ? IT : 4];
+    int aoff[OT], boff[IT < 4 ? IT : 4], bpos[2][2];
 #pragma unroll
     for (int a = 0; a < OT; ++a) aoff[a] = dwh_off<NOW>(8 * (g >> 1) + q, (32 * OT * w + 32 * a) + 16 * (g & 1) + 4 * pp);
 #pragma unroll
     for (int b = 0; b < (IT < 4 ? IT : 4); ++b) boff[b] = ZB + dwh_off<NIP>(8 * (g >> 1) + q, 32 * b + 16 * (g & 1) + 4 * pp);
+    {
+        const int k = pp + 4 * (g & 1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) bpos[ks][j] = (k * 32 + ((8 * (g >> 1) + q + 16 * ks + 4 * j) ^ (4 * k))) * 8;
+    }
 
     u32x4 rz[2][ZC], rx[2][XC];
     auto fetch = [&](int slot, int64_t stage) {
-        const int64_t sb = s0 + 32 * stage;
+        const int64_t sb = s0 + 32 * stage;                         // s0 and per_wg are multiples of 32: sb is a block start
 #pragma unroll
         for (int i = 0; i < ZC; ++i) {
-            const int id = tid + 256 * i, row = id / (NOW / 8), ch = id % (NOW / 8);
-            rz[slot][i] = sb + row < s1 ? *reinterpret_cast<const u32x4*>(dZ + (sb + row) * ldz + 8 * ch) : u32x4{0u, 0u, 0u, 0u};
+            const int id = tid + 256 * i;
+            if (ZBLK) {
+                rz[slot][i] = sb < s1 ? *reinterpret_cast<const u32x4*>(dZ + (sb >> 5) * (int64_t)(NOW * 32) + 8 * id) : u32x4{0u, 0u, 0u, 0u};
+            } else {
+                const int row = id / (NOW / 8), ch = id % (NOW / 8);
+                rz[slot][i] = sb + row < s1 ? *reinterpret_cast<const u32x4*>(dZ + (sb + row) * ldz + 8 * ch) : u32x4{0u, 0u, 0u, 0u};
+            }
         }
 #pragma unroll
         for (int i = 0; i < XC; ++i) {
-            const int id = tid + 256 * i, row = id / (NIP / 8), ch = id % (NIP / 8);
-            rx[slot][i] = sb + row < s1 ? *reinterpret_cast<const u32x4*>(X + (sb + row) * ldx + 8 * ch) : u32x4{0u, 0u, 0u, 0u};
+            const int id = tid + 256 * i;
+            if (XBLK) {
+                rx[slot][i] = sb < s1 ? *reinterpret_cast<const u32x4*>(X + (sb >> 5) * (int64_t)(NIP * 32) + 8 * id) : u32x4{0u, 0u, 0u, 0u};
+            } else {
+                const int row = id / (NIP / 8), ch = id % (NIP / 8);
+                rx[slot][i] = sb + row < s1 ? *reinterpret_cast<const u32x4*>(X + (sb + row) * ldx + 8 * ch) : u32x4{0u, 0u, 0u, 0u};
+            }
         }
     };
     auto stage_in = [&](int slot, int buf) {
 #pragma unroll
         for (int i = 0; i < ZC; ++i) {
             const int id = tid + 256 * i, row = id / (NOW / 8), ch = id % (NOW / 8);
-            *reinterpret_cast<u32x4*>(&lds[buf][dwh_off<NOW>(row, 8 * ch)]) = rz[slot][i];
+            *reinterpret_cast<u32x4*>(&lds[buf][ZBLK ? 16 * id : dwh_off<NOW>(row, 8 * ch)]) = rz[slot][i];
         }
 #pragma unroll
         for (int i = 0; i < XC; ++i) {
             const int id = tid + 256 * i, row = id / (NIP / 8), ch = id % (NIP / 8);
-            *reinterpret_cast<u32x4*>(&lds[buf][ZB + dwh_off<NIP>(row, 8 * ch)]) = rx[slot][i];
+            *reinterpret_cast<u32x4*>(&lds[buf][ZB + (XBLK ? 16 * id : dwh_off<NIP>(row, 8 * ch))]) = rx[slot][i];
         }
     };
     auto compute = [&](int buf) {
+        const unsigned lb = lbase + buf * (ZB + XB);
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             h16x8 af[OT];
 #pragma unroll
             for (int a = 0; a < OT; ++a) {
-                af[a] = dwh_frag(lbase + buf * (ZB + XB) + aoff[a] + 16 * ks * ZROW, 4 * ZROW);
+                if (ZBLK) af[a] = dwh_frag2(lb + (OT * w + a) * 2048 + bpos[ks][0], lb + (OT * w + a) * 2048 + bpos[ks][1]);
+                else af[a] = dwh_frag2(lb + aoff[a] + 16 * ks * ZROW, lb + aoff[a] + 16 * ks * ZROW + 4 * ZROW);
 #pragma unroll
                 for (int j = 0; j < 8; j += 2)
                     bsum[a] = __builtin_amdgcn_fdot2(h16x2{af[a][j], af[a][j + 1]}, h16x2{(_Float16)1.0f, (_Float16)1.0f}, bsum[a], false);
             }
 #pragma unroll
             for (int it = 0; it < IT; ++it) {
-                const h16x8 bf = dwh_frag(lbase + buf * (ZB + XB) + boff[it & 3] + (it >> 2) * (32 * 256) + 16 * ks * XROW, 4 * XROW);
+                h16x8 bf;
+                if (XBLK) bf = dwh_frag2(lb + ZB + it * 2048 + bpos[ks][0], lb + ZB + it * 2048 + bpos[ks][1]);
+                else {
+                    const unsigned ba = lb + boff[it & 3] + (it >> 2) * (32 * 256) + 16 * ks * XROW;
+                    bf = dwh_frag2(ba, ba + 4 * XROW);
+                }
 #pragma unroll
                 for (int a = 0; a < OT; ++a) acc[a][it] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[a], bf, acc[a][it], 0, 0, 0);
             }
@@ -576,8 +608,8 @@ __global__ __launch_bounds__(256) void mlp_dwh_kernel(const _Float16* __restrict
     }
 }
 
-// head layers with f16 activations: mlp_dw_head_kernel reading X as halves
-template <int NI>
+// head layers with f16 activations: mlp_dw_head_kernel reading X as halves (XBLK: blocked layout, see mlp_dwh_kernel)
+template <int NI, bool XBLK>
 __global__ __launch_bounds__(NI) void mlp_dwh_head_kernel(const float* __restrict__ dY, int64_t ldy, int n_out,
                                                            const _Float16* __restrict__ X, int64_t ldx, int64_t P,
                                                            int64_t per_wg, float* __restrict__ part,
@@ -586,7 +618,9 @@ __global__ __launch_bounds__(NI) void mlp_dwh_head_kernel(const float* __restric
     const int64_t s0 = (int64_t)blockIdx.x * per_wg;
     const int64_t s1 = s0 + per_wg < P ? s0 + per_wg : P;
     float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f, b = 0.f;
-    const _Float16* xp = X + i;
+    const int kx = ((i & 31) >> 3) * 2 + ((i >> 2) & 1);             // blocked: feature group of column i, slot swizzle 4 kx
+    const _Float16* xp = XBLK ? X + (i >> 5) * 1024 + kx * 128 + (i & 3) : X + i;
+    auto at = [&](int64_t s) { return XBLK ? (float)xp[(s >> 5) * (int64_t)(NI * 32) + (((int)(s & 31)) ^ (4 * kx)) * 4] : (float)xp[s * ldx]; };
     auto step = [&](int64_t s, float x) {
         const float* g = dY + s * ldy;
         const float g0 = g[0], g1 = n_out > 1 ? g[1] : 0.f, g2 = n_out > 2 ? g[2] : 0.f, g3 = n_out > 3 ? g[3] : 0.f;
@@ -600,11 +634,11 @@ __global__ __launch_bounds__(NI) void mlp_dwh_head_kernel(const float* __restric
     for (; s + 8 <= s1; s += 8) {
         float x[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) x[u] = (float)xp[(s + u) * ldx];
+        for (int u = 0; u < 8; ++u) x[u] = at(s + u);
 #pragma unroll
         for (int u = 0; u < 8; ++u) step(s + u, x[u]);
     }
-    for (; s < s1; ++s) step(s, (float)xp[s * ldx]);
+    for (; s < s1; ++s) step(s, at(s));
     float* out = part + (int64_t)blockIdx.x * 4 * NI;
     out[i] = a0;
     out[NI + i] = a1;
@@ -988,9 +1022,11 @@ extern "C" size_t hnrf_mlp_dw_h_workspace_bytes(int64_t P, int n_out, int n_in) 
 }
 
 extern "C" int hnrf_mlp_dw_h(const void* dZ, int64_t ldz, const void* X, int64_t ldx, int64_t P, int n_out, int n_in,
-                             const float* dz_scale, float* dW, int64_t ldw, float* db, void* workspace,
+                             int layout, const float* dz_scale, float* dW, int64_t ldw, float* db, void* workspace,
                              size_t workspace_bytes, void* stream) {
     HNRF_REQUIRE(dZ && X && dW && workspace, HNRF_E_ARG, "hnrf_mlp_dw_h: null pointer");
+    HNRF_REQUIRE((layout & ~(HNRF_DWH_DZ_BLOCKED | HNRF_DWH_X_BLOCKED)) == 0, HNRF_E_ARG, "hnrf_mlp_dw_h: bad layout %d", layout);
+    const bool zb = layout & HNRF_DWH_DZ_BLOCKED, xb = layout & HNRF_DWH_X_BLOCKED;
     DwPlan pl;
     HNRF_REQUIRE(P > 0 && dwh_plan(P, n_out, n_in, pl), HNRF_E_UNSUPPORTED,
                  "hnrf_mlp_dw_h: shape P=%lld n_out=%d n_in=%d not built (n_out 128|256 with n_in 128|256|<=64; n_out <= 4 "
@@ -1002,24 +1038,33 @@ extern "C" int hnrf_mlp_dw_h(const void* dZ, int64_t ldz, const void* X, int64_t
     hipStream_t st = (hipStream_t)stream;
     if (n_out <= 4) {
         // dZ is the fp32 [P, n_out] gradient at the head's output; X the f16 activations of the last hidden layer
-        HNRF_REQUIRE(ldz >= n_out && ldx >= n_in && ldw >= n_in, HNRF_E_ARG, "hnrf_mlp_dw_h: row stride below width");
-        if (n_in == 256)
-            hipLaunchKernelGGL(mlp_dwh_head_kernel<256>, dim3(pl.nsplit), dim3(256), 0, st, (const float*)dZ, ldz, n_out,
-                               (const _Float16*)X, ldx, P, pl.per_wg, part, db ? dbpart : nullptr);
-        else
-            hipLaunchKernelGGL(mlp_dwh_head_kernel<128>, dim3(pl.nsplit), dim3(128), 0, st, (const float*)dZ, ldz, n_out,
-                               (const _Float16*)X, ldx, P, pl.per_wg, part, db ? dbpart : nullptr);
+        HNRF_REQUIRE(!zb && ldz >= n_out && (xb || ldx >= n_in) && ldw >= n_in, HNRF_E_ARG, "hnrf_mlp_dw_h: bad head operands");
+#define HNRF_DWHH(NI, XB)                                                                                              \
+    hipLaunchKernelGGL((mlp_dwh_head_kernel<NI, XB>), dim3(pl.nsplit), dim3(NI), 0, st, (const float*)dZ, ldz, n_out, \
+                       (const _Float16*)X, ldx, P, pl.per_wg, part, db ? dbpart : nullptr)
+        if (n_in == 256) { if (xb) HNRF_DWHH(256, true); else HNRF_DWHH(256, false); }
+        else { if (xb) HNRF_DWHH(128, true); else HNRF_DWHH(128, false); }
+#undef HNRF_DWHH
     } else {
-        HNRF_REQUIRE(ldz >= pl.now && ldx >= pl.nip && ldw >= n_in, HNRF_E_ARG,
+        HNRF_REQUIRE((zb || ldz >= pl.now) && (xb || ldx >= pl.nip) && ldw >= n_in, HNRF_E_ARG,
                      "hnrf_mlp_dw_h: row stride below the padded width (X rows must hold %d halves)", pl.nip);
-        HNRF_REQUIRE((((uintptr_t)dZ | (uintptr_t)X) & 15) == 0 && ldz % 8 == 0 && ldx % 8 == 0, HNRF_E_ARG,
+        HNRF_REQUIRE((((uintptr_t)dZ | (uintptr_t)X) & 15) == 0 && (zb || ldz % 8 == 0) && (xb || ldx % 8 == 0), HNRF_E_ARG,
                      "hnrf_mlp_dw_h: dZ and X must be 16-byte aligned with row strides that are multiples of 8 halves");
-#define HNRF_DWH(OT, IT)                                                                                            \
-    hipLaunchKernelGGL((mlp_dwh_kernel<OT, IT>), dim3(pl.nsplit), dim3(256), 0, st, (const _Float16*)dZ, ldz,       \
+        HNRF_REQUIRE(!xb || pl.nip >= 128, HNRF_E_UNSUPPORTED, "hnrf_mlp_dw_h: blocked X needs n_in 128 | 256");
+#define HNRF_DWH1(OT, IT, ZB_, XB_)                                                                                    \
+    hipLaunchKernelGGL((mlp_dwh_kernel<OT, IT, ZB_, XB_>), dim3(pl.nsplit), dim3(256), 0, st, (const _Float16*)dZ, ldz, \
                        (const _Float16*)X, ldx, P, pl.per_wg, dz_scale, part, db ? dbpart : nullptr)
+#define HNRF_DWH(OT, IT)                                                       \
+    do {                                                                       \
+        if (zb && xb) { if (IT >= 4) HNRF_DWH1(OT, (IT >= 4 ? IT : 4), true, true); } \
+        else if (zb) HNRF_DWH1(OT, IT, true, false);                           \
+        else HNRF_DWH1(OT, IT, false, false);                                  \
+    } while (0)
+        HNRF_REQUIRE(zb || !xb, HNRF_E_UNSUPPORTED, "hnrf_mlp_dw_h: blocked X with row-major dZ is not built");
         if (n_out == 256) { if (pl.nip == 256) HNRF_DWH(2, 8); else if (pl.nip == 128) HNRF_DWH(2, 4); else HNRF_DWH(2, 2); }
         else { if (pl.nip == 256) HNRF_DWH(1, 8); else if (pl.nip == 128) HNRF_DWH(1, 4); else HNRF_DWH(1, 2); }
 #undef HNRF_DWH
+#undef HNRF_DWH1
     }
     int rc = check_launch("hnrf_mlp_dw_h");
     if (rc) return rc;
@@ -1090,22 +1135,25 @@ extern "C" int hnrf_canonical_bwd(const float* xyz, const float* d_raw, const ui
                                   int mode, const float* d_raw_amax, int64_t P, float* dZ, float* d_xyz,
                                   float* dz_amax, void* stream) {
     HNRF_REQUIRE(xyz && d_raw && relu_bits && packed && dZ && d_xyz, HNRF_E_ARG, "hnrf_canonical_bwd: null pointer");
-    HNRF_REQUIRE(mode == HNRF_MLP_F32 || mode == HNRF_MLP_F16X3, HNRF_E_UNSUPPORTED,
+    HNRF_REQUIRE(mode == HNRF_MLP_F32 || mode == HNRF_MLP_F16X3 || mode == HNRF_MLP_F16X3_H, HNRF_E_UNSUPPORTED,
                  "hnrf_canonical_bwd: mode %d not built", mode);
-    HNRF_REQUIRE(mode != HNRF_MLP_F16X3 || d_raw_amax, HNRF_E_ARG,
+    HNRF_REQUIRE(mode == HNRF_MLP_F32 || d_raw_amax, HNRF_E_ARG,
                  "hnrf_canonical_bwd: HNRF_MLP_F16X3 needs d_raw_amax (device scalar >= max |d_raw|)");
+    HNRF_REQUIRE(mode != HNRF_MLP_F16X3_H || dz_amax, HNRF_E_ARG, "hnrf_canonical_bwd: HNRF_MLP_F16X3_H needs dz_amax ([8] scales out)");
     HNRF_REQUIRE(P >= 0, HNRF_E_ARG, "hnrf_canonical_bwd: bad P");
     HNRF_REQUIRE((((uintptr_t)d_raw | (uintptr_t)relu_bits | (uintptr_t)dZ | (uintptr_t)packed) & 15) == 0, HNRF_E_ARG,
                  "hnrf_canonical_bwd: d_raw, relu_bits, dZ, packed must be 16-byte aligned");
     if (P == 0) return HNRF_OK;
     const int64_t blocks = (P + 127) / 128;
     HNRF_REQUIRE(blocks < 2147483647LL, HNRF_E_ARG, "hnrf_canonical_bwd: too many samples");
+    if (mode == HNRF_MLP_F16X3_H)
+        return canonical16_bwd(xyz, d_raw, relu_bits, packed, P, d_raw_amax, dZ, d_xyz, dz_amax, 1, (hipStream_t)stream);
     if (dz_amax && hipMemsetAsync(dz_amax, 0, 8 * HNRF_AMAX_SLOTS * sizeof(float), (hipStream_t)stream) != hipSuccess) {
         set_error("hnrf_canonical_bwd: memset failed");
         return HNRF_E_LAUNCH;
     }
     if (mode == HNRF_MLP_F16X3)
-        return canonical16_bwd(xyz, d_raw, relu_bits, packed, P, d_raw_amax, dZ, d_xyz, dz_amax, (hipStream_t)stream);
+        return canonical16_bwd(xyz, d_raw, relu_bits, packed, P, d_raw_amax, dZ, d_xyz, dz_amax, 0, (hipStream_t)stream);
     hipLaunchKernelGGL(canonical_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, xyz,
                        (const float4*)d_raw, relu_bits, (const float*)packed, P, dZ, d_xyz, dz_amax);
     return check_launch("hnrf_canonical_bwd");
@@ -1115,9 +1163,10 @@ extern "C" int hnrf_nonrigid_bwd(const float* x_skel, const float* hann_w, const
                                  const uint32_t* relu_bits, const void* packed, int mode,
                                  const float* d_xyz_amax, int64_t P, float* dZ, float* d_x_skel, float* dz_amax,
                                  void* stream) {
-    HNRF_REQUIRE(mode == HNRF_MLP_F32 || mode == HNRF_MLP_F16X3, HNRF_E_UNSUPPORTED, "hnrf_nonrigid_bwd: mode %d not built", mode);
-    HNRF_REQUIRE(mode != HNRF_MLP_F16X3 || d_xyz_amax, HNRF_E_ARG,
+    HNRF_REQUIRE(mode == HNRF_MLP_F32 || mode == HNRF_MLP_F16X3 || mode == HNRF_MLP_F16X3_H, HNRF_E_UNSUPPORTED, "hnrf_nonrigid_bwd: mode %d not built", mode);
+    HNRF_REQUIRE(mode == HNRF_MLP_F32 || d_xyz_amax, HNRF_E_ARG,
                  "hnrf_nonrigid_bwd: HNRF_MLP_F16X3 needs d_xyz_amax (device scalar >= max |d_xyz|)");
+    HNRF_REQUIRE(mode != HNRF_MLP_F16X3_H || dz_amax, HNRF_E_ARG, "hnrf_nonrigid_bwd: HNRF_MLP_F16X3_H needs dz_amax ([6] scales out)");
     HNRF_REQUIRE(x_skel && hann_w && d_xyz && relu_bits && packed && dZ && d_x_skel, HNRF_E_ARG,
                  "hnrf_nonrigid_bwd: null pointer");
     HNRF_REQUIRE(P >= 0, HNRF_E_ARG, "hnrf_nonrigid_bwd: bad P");
@@ -1126,12 +1175,15 @@ extern "C" int hnrf_nonrigid_bwd(const float* x_skel, const float* hann_w, const
     if (P == 0) return HNRF_OK;
     const int64_t blocks = (P + 127) / 128;
     HNRF_REQUIRE(blocks < 2147483647LL, HNRF_E_ARG, "hnrf_nonrigid_bwd: too many samples");
+    if (mode == HNRF_MLP_F16X3_H)
+        return nonrigid16_bwd(x_skel, hann_w, d_xyz, relu_bits, packed, P, d_xyz_amax, dZ, d_x_skel, dz_amax, 1,
+                              (hipStream_t)stream);
     if (dz_amax && hipMemsetAsync(dz_amax, 0, 6 * HNRF_AMAX_SLOTS * sizeof(float), (hipStream_t)stream) != hipSuccess) {
         set_error("hnrf_nonrigid_bwd: memset failed");
         return HNRF_E_LAUNCH;
     }
     if (mode == HNRF_MLP_F16X3)
-        return nonrigid16_bwd(x_skel, hann_w, d_xyz, relu_bits, packed, P, d_xyz_amax, dZ, d_x_skel, dz_amax,
+        return nonrigid16_bwd(x_skel, hann_w, d_xyz, relu_bits, packed, P, d_xyz_amax, dZ, d_x_skel, dz_amax, 0,
                               (hipStream_t)stream);
     hipLaunchKernelGGL(nonrigid_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x_skel, hann_w,
                        d_xyz, relu_bits, (const float*)packed, P, dZ, d_x_skel, dz_amax);

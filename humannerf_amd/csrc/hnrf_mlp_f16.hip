@@ -40,6 +40,17 @@ constexpr float LO_INV = 1.0f / 2048.0f;
 
 enum { PE16_NONE = 0, PE16_CANONICAL = 1, PE16_NONRIGID = 2 };
 
+// what layer16 stores besides feeding the next layer (template parameter SAVE)
+enum { SV_NONE = 0,
+       SV_ACT = 1,      // training forward: fp32 activations + sign masks
+       SV_DZ = 2,       // backward chain: relu' from the sign mask, fp32 dZ (un-scaled)
+       SV_PE = 3,       // backward chain, positional-encoding stage: fp32 values to registers
+       SV_ACT_H = 4,    // like SV_ACT with f16 activations
+       SV_DZ_H = 5 };   // like SV_DZ with f16 dZ in the chain's power-of-two scaled domain
+__host__ __device__ constexpr bool sv_fwd(int s) { return s == SV_ACT || s == SV_ACT_H; }
+__host__ __device__ constexpr bool sv_bwd(int s) { return s == SV_DZ || s == SV_DZ_H; }
+__host__ __device__ constexpr bool sv_has_bias(int s) { return s == SV_NONE || sv_fwd(s); }
+
 // hidden feature contracted by element j of k-step ks on lane half h
 __host__ __device__ inline int hid_feat16(int ks, int j, int h) {
     return 32 * (ks >> 1) + 16 * (ks & 1) + 8 * (j >> 2) + 4 * h + (j & 3);
@@ -63,7 +74,20 @@ struct PackLayer16 {
     int pe_kind, a_col0, b_col0, fold_cols;
     int64_t off;               // byte offset of the layer's first slab
     int64_t bias_off;          // byte offset of the layer's first 128-B bias record
+    int head_scale;            // 1 (head layers): weights stored x 2^k, 2^-k left in float 8 of the bias record
 };
+
+// Power-of-two exponent that brings a layer with abnormally small or large weights back to the usual magnitude
+// (max |w| in [1/8, 1/4)); 0 for anything between 2^-9 and 2^3.  The split v = hi + lo 2^-11 has an ABSOLUTE floor
+// (f16 subnormals): a layer of +-1e-5 -- the reference initialises the last layer of the non-rigid MLP and of the pose
+// decoder like that (mlp_offset.py:60-66) -- would keep ~17 of its 22 bits; scaled by 2^14 it keeps all of them, and
+// the scale is exact and folded back where the values leave the kernel.
+__host__ __device__ inline int layer_exponent(float amax) {
+    if (!(amax > 0.f) || !(amax < 3.0e38f)) return 0;
+    int ex = 0;
+    (void)frexpf(amax, &ex);
+    return (ex < -8 || ex > 3) ? -2 - ex : 0;
+}
 
 // one thread per f16 PAIR of the weight image (slab = 2 NK KiB) + the layer's bias records
 __global__ void pack_layer16_kernel(PackLayer16 d, const float* __restrict__ cond, char* __restrict__ packed) {
@@ -71,6 +95,19 @@ __global__ void pack_layer16_kernel(PackLayer16 d, const float* __restrict__ con
     const int slab_units = 2 * NK * 256;                          // 4-byte units per slab
     const int64_t n = (int64_t)d.NT * slab_units;
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int kexp = 0;
+    if (d.head_scale) {                                            // (<= 4 x 256 weights: every block finds the maximum itself)
+        __shared__ float red[256];
+        float m = 0.f;
+        for (int e = threadIdx.x; e < d.n_out * d.n_in; e += blockDim.x) m = fmaxf(m, fabsf(d.W[e]));
+        red[threadIdx.x] = m;
+        __syncthreads();
+        for (int st = 128; st >= 1; st >>= 1) {
+            if ((int)threadIdx.x < st) red[threadIdx.x] = fmaxf(red[threadIdx.x], red[threadIdx.x + st]);
+            __syncthreads();
+        }
+        kexp = layer_exponent(red[0]);
+    }
     if (i < (int64_t)d.NT * 32) {                                  // bias: 32 fp32 per tile
         const int row = (int)i;
         float v = 0.f;
@@ -78,6 +115,7 @@ __global__ void pack_layer16_kernel(PackLayer16 d, const float* __restrict__ con
             v = d.b[row];
             for (int c = 0; c < d.fold_cols; ++c) v += d.W[(int64_t)row * d.n_in + c] * cond[c];
         }
+        if (d.head_scale && i == 8) v = ldexpf(1.0f, -kexp);
         *reinterpret_cast<float*>(packed + d.bias_off + i * 4) = v;
     }
     if (i >= n) return;
@@ -101,7 +139,7 @@ __global__ void pack_layer16_kernel(PackLayer16 d, const float* __restrict__ con
             col = d.b_col0 + hid_feat16(ks - d.NKA, j, h);
         }
         float w = 0.f;
-        if (row < d.n_out && col >= 0 && col < d.n_in) w = d.W[(int64_t)row * d.n_in + col];
+        if (row < d.n_out && col >= 0 && col < d.n_in) w = ldexpf(d.W[(int64_t)row * d.n_in + col], kexp);
         const _Float16 hi = (_Float16)w;
         const _Float16 lo = (_Float16)((w - (float)hi) * LO_SCALE);
         outv[e] = part ? lo : hi;
@@ -250,8 +288,8 @@ __device__ __forceinline__ void epi_pair(const f32x16& a1, const f32x16& a2, int
 
 // epi_pair that also hands back the two activations (training variant stores them)
 template <bool RELU>
-__device__ __forceinline__ void epi_pair_x(const f32x16& a1, const f32x16& a2, int i, h16x8& hi, h16x8& lo, float& x0o,
-                                           float& x1o) {
+__device__ __forceinline__ h16x2 epi_pair_x(const f32x16& a1, const f32x16& a2, int i, h16x8& hi, h16x8& lo, float& x0o,
+                                            float& x1o) {
     float x0 = fmaf(a2[2 * i], LO_INV, a1[2 * i]);
     float x1 = fmaf(a2[2 * i + 1], LO_INV, a1[2 * i + 1]);
     if (RELU) {
@@ -270,14 +308,19 @@ __device__ __forceinline__ void epi_pair_x(const f32x16& a1, const f32x16& a2, i
     lo[e + 1] = ll[1];
     x0o = x0;
     x1o = x1;
+    return hh;
 }
 
 // Training variant (SAVE): where this lane's activations go.  row = the lane's row of the layer's [P, width]
 // fp32 activation matrix (+ 4 h floats: the lane half's column offset), bits = its words of the sign mask.
 // EVERY lane stores (lanes past P carry a copy of sample P-1 and rewrite its values): the number of VMEM
 // operations per tile must be the same for all waves, the hand-counted vmcnt waits include them.
+typedef _Float16 h16x4 __attribute__((ext_vector_type(4)));
+
 struct SaveCtx {
     float* row;
+    _Float16* rowh;            // SV_ACT_H / SV_DZ_H: the wave's block of the blocked f16 matrix (+ 128 h), see save_pair_bh
+    int cx;                    // c ^ 4 h
     uint32_t* bits;
     float sv0, sv1;            // even pair of the current float4
     // backward chain (layer16 SAVE = 2 / 3): sign-mask words of the stage, 1 / scale of the gradient, running
@@ -333,6 +376,61 @@ __device__ __forceinline__ void save_pair(SaveCtx& sc, uint32_t (&bw)[NW], int t
     }
 }
 
+// f16 forms (SV_ACT_H / SV_DZ_H): 4 halves (8 bytes) per store, same number of stores per tile as the fp32 forms (the
+// hand-counted vmcnt waits do not change).  What is stored is EXACTLY the hi part of the split the next layer consumes
+// (hi = f16(x) is the f16 rounding of the value), so the store takes its two dwords straight out of the B-operand
+// fragment: no conversion, no extra VALU.  dZ is stored as it stands in the chain (scaled by a power of two that the
+// weight-gradient kernel divides out), activations un-scaled.
+// BLOCKED layout (HNRF_DWH_*_BLOCKED in hnrf_mlp_dw_h): the matrix of one layer is a sequence of 32-sample blocks, a
+// block a sequence of 32-feature tiles of 2 KiB laid out [k = 2 g + h: 8 groups of 4 features][32 sample slots][4 halves]
+// with sample c in slot c ^ 4 k -- the order in which a wave holds it (lane (c, h), registers 4 g .. 4 g + 3), so that
+// every store instruction writes 512 contiguous bytes (row-major [sample][feature] would scatter each instruction over
+// 32 rows: 32 partial cache-line writes), and the slot swizzle makes the image conflict-free for the weight-gradient
+// kernel's transposed LDS reads as it stands (it is copied to LDS linearly).
+// SaveCtx::rowh = block base + 128 h (halves), SaveCtx::cx = c ^ 4 h.
+// forward form: the two dwords come straight out of the finished B-operand fragment (i odd: pairs i - 1, i)
+__device__ __forceinline__ void store_frag_h(_Float16* rowh, int cx, int t, int i, const h16x8& frag) {
+    const int g = i >> 1, e = 2 * (i & 3);
+    *reinterpret_cast<h16x4*>(rowh + 1024 * t + 256 * g + ((cx ^ (8 * g)) << 2)) = h16x4{frag[e - 2], frag[e - 1], frag[e], frag[e + 1]};
+}
+typedef unsigned int u32x2s __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void store_pair_h(_Float16* rowh, int cx, unsigned& svu, int t, int i, h16x2 hh) {     // hh: the hi parts of pair i
+    const unsigned u = __builtin_bit_cast(unsigned, hh);
+    if (i & 1) {
+        const int g = i >> 1;
+        *reinterpret_cast<u32x2s*>(rowh + 1024 * t + 256 * g + ((cx ^ (8 * g)) << 2)) = u32x2s{svu, u};
+    } else {
+        svu = u;
+    }
+}
+
+// sign mask of the f16 forms: acc = 2 acc + [x > 0] (v_cmp + v_addc: 2 VALU per value).  After the 16 values of a tile
+// in register order, value r sits in bit 15 - r; a word takes two tiles, the even one in the upper half.
+__device__ __forceinline__ void push_bit(uint32_t& acc, float x) {
+    asm("v_cmp_lt_f32 vcc, 0, %1\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(acc) : "v"(x) : "vcc");
+}
+
+// Backward epilogue of the f16 form: relu' from that mask (word already shifted so that the tile's bit 15 - r is value
+// r's): a 1-bit signed field extract gives 0 / -1, one AND applies it (2 VALU per value).
+__device__ __forceinline__ h16x2 epi_pair_mh(const f32x16& a1, const f32x16& a2, int i, uint32_t mword, h16x8& hi, h16x8& lo) {
+    float x0 = fmaf(a2[2 * i], LO_INV, a1[2 * i]);
+    float x1 = fmaf(a2[2 * i + 1], LO_INV, a1[2 * i + 1]);
+    x0 = __builtin_amdgcn_fmed3f(x0, -65504.f, 65504.f);
+    x1 = __builtin_amdgcn_fmed3f(x1, -65504.f, 65504.f);
+    x0 = __uint_as_float(__float_as_uint(x0) & (uint32_t)__builtin_amdgcn_sbfe((int)mword, 15 - 2 * i, 1));
+    x1 = __uint_as_float(__float_as_uint(x1) & (uint32_t)__builtin_amdgcn_sbfe((int)mword, 14 - 2 * i, 1));
+    const h16x2 hh = __builtin_convertvector(f32x2{x0, x1}, h16x2);
+    const float r0 = fmaf((float)hh[0], -LO_SCALE, x0 * LO_SCALE);
+    const float r1 = fmaf((float)hh[1], -LO_SCALE, x1 * LO_SCALE);
+    const h16x2 ll = __builtin_convertvector(f32x2{r0, r1}, h16x2);
+    const int e = 2 * (i & 3);
+    hi[e] = hh[0];
+    hi[e + 1] = hh[1];
+    lo[e] = ll[0];
+    lo[e + 1] = ll[1];
+    return hh;
+}
+
 // One layer.  K order = [PE part (NKA k-steps, B operand from the LDS stash) | hidden part
 // (NKB k-steps, B operand from registers)].  The layer's NT tiles travel TPS per slab.
 // nb1 / nb2: blocks of the first / second slab that follow this layer in the image (0 = none).
@@ -351,7 +449,7 @@ template <int NT, int TPS, int NKA, int NKB, bool RELU, int SAVE = 0, bool PEND_
 __device__ __forceinline__ void layer16(Pipe& p, int nb1, int nb2, h16x8 (&bh)[NB], h16x8 (&bl)[NB],
                                         h16x8 (&oh)[NO], h16x8 (&ol)[NO], float (&last)[16], SaveCtx* sc = nullptr,
                                         f32x16* pend1 = nullptr, f32x16* pend2 = nullptr) {
-    static_assert(!(PEND_IN || DEFER) || SAVE == 0, "deferred epilogues exist in the inference form only");
+    static_assert(!(PEND_IN || DEFER) || SAVE == SV_NONE, "deferred epilogues exist in the inference form only");
     static_assert(!PEND_IN || NKB >= 2, "a pending tile fills the last two hidden fragments");
     static_assert(NB >= (NKB > 0 ? NKB : 1) && NO >= 2 * NT && NT % TPS == 0, "bad layer shape");
     constexpr int NK = NKA + NKB;
@@ -364,6 +462,11 @@ __device__ __forceinline__ void layer16(Pipe& p, int nb1, int nb2, h16x8 (&bh)[N
     f32x16 nbias = pacc1;                    // bias of the NEXT tile: the table is resident in LDS, so it is read
                                              // during the current tile instead of on the critical path behind the barrier
     uint32_t bw[(NT + 1) / 2];               // SAVE: sign mask of this layer's outputs (this lane half)
+    // f16 forms: locals, not SaveCtx fields (the struct is reached through a pointer: fields written here would
+    // live in scratch memory)
+    _Float16* const rowh = (SAVE == SV_ACT_H || SAVE == SV_DZ_H) ? sc->rowh : nullptr;
+    const int cxh = (SAVE == SV_ACT_H || SAVE == SV_DZ_H) ? sc->cx : 0;
+    unsigned svu = 0u;
 #pragma unroll
     for (int i = 0; i < (NT + 1) / 2; ++i) bw[i] = 0u;
 #pragma unroll
@@ -390,7 +493,7 @@ __device__ __forceinline__ void layer16(Pipe& p, int nb1, int nb2, h16x8 (&bh)[N
             asm volatile("" : "+v"(cur), "+v"(pe));
             f32x16 acc1 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
             f32x16 acc2 = acc1;
-            if (NT > 1 && SAVE < 2) {                      // (the backward stages have no bias)
+            if (NT > 1 && sv_has_bias(SAVE)) {             // (the backward stages have no bias)
                 if (t == 0) {
                     const unsigned bp = p.lds_base + p.bias_off + tt * 128 + (lane >> 5) * 16;
                     const f32x4 b0 = lds_ld4f(bp), b1 = lds_ld4f(bp + 32), b2 = lds_ld4f(bp + 64), b3 = lds_ld4f(bp + 96);
@@ -438,7 +541,7 @@ __device__ __forceinline__ void layer16(Pipe& p, int nb1, int nb2, h16x8 (&bh)[N
                 acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, xh, acc1, 0, 0, 0);
                 acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, xl, acc2, 0, 0, 0);
                 acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, xh, acc2, 0, 0, 0);
-                if (NT > 1 && SAVE < 2 && ks == NK - 1 && t + 1 < NT) {
+                if (NT > 1 && sv_has_bias(SAVE) && ks == NK - 1 && t + 1 < NT) {
                     const unsigned bn = p.lds_base + p.bias_off + (tt + 1) * 128 + (lane >> 5) * 16;   // (tt + 1 == TPS: next slab's first)
                     const f32x4 b0 = lds_ld4f(bn), b1 = lds_ld4f(bn + 32), b2 = lds_ld4f(bn + 64), b3 = lds_ld4f(bn + 96);
                     nbias = f32x16{b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w,
@@ -469,24 +572,34 @@ __device__ __forceinline__ void layer16(Pipe& p, int nb1, int nb2, h16x8 (&bh)[N
 #pragma unroll
                     for (int i = 0; i < 8; ++i)
                         if ((i * NK) / 8 == ks) {
-                            if constexpr (SAVE == 1) {
+                            if constexpr (SAVE == SV_ACT) {
                                 float x0, x1;
                                 epi_pair_x<RELU>(pacc1, pacc2, i, oh[2 * (t - 1) + (i >> 2)], ol[2 * (t - 1) + (i >> 2)],
                                                  x0, x1);
                                 save_pair(*sc, bw, t - 1, i, x0, x1);
-                            } else if constexpr (SAVE == 2) {
+                            } else if constexpr (SAVE == SV_ACT_H) {
+                                float x0, x1;
+                                epi_pair_x<RELU>(pacc1, pacc2, i, oh[2 * (t - 1) + (i >> 2)], ol[2 * (t - 1) + (i >> 2)], x0, x1);
+                                push_bit(bw[(t - 1) >> 1], x0);
+                                push_bit(bw[(t - 1) >> 1], x1);
+                                if (i & 1) store_frag_h(rowh, cxh, t - 1, i, oh[2 * (t - 1) + (i >> 2)]);
+                            } else if constexpr (SAVE == SV_DZ) {
                                 float x0, x1;
                                 epi_pair_m(pacc1, pacc2, i, sc->mask[(t - 1) >> 1] >> (16 * ((t - 1) & 1)),
                                            oh[2 * (t - 1) + (i >> 2)], ol[2 * (t - 1) + (i >> 2)], x0, x1);
                                 save_pair_b(*sc, t - 1, i, x0, x1);
-                            } else if constexpr (SAVE == 3) {
+                            } else if constexpr (SAVE == SV_DZ_H) {
+                                const h16x2 hh = epi_pair_mh(pacc1, pacc2, i, sc->mask[(t - 1) >> 1] >> (16 * (1 - ((t - 1) & 1))),
+                                                             oh[2 * (t - 1) + (i >> 2)], ol[2 * (t - 1) + (i >> 2)]);
+                                store_pair_h(rowh, cxh, svu, t - 1, i, hh);
+                            } else if constexpr (SAVE == SV_PE) {
                                 sc->fout[16 * (t - 1) + 2 * i] = fmaf(pacc2[2 * i], LO_INV, pacc1[2 * i]);
                                 sc->fout[16 * (t - 1) + 2 * i + 1] = fmaf(pacc2[2 * i + 1], LO_INV, pacc1[2 * i + 1]);
                             } else
                             epi_pair<RELU>(pacc1, pacc2, i, oh[2 * (t - 1) + (i >> 2)], ol[2 * (t - 1) + (i >> 2)]);
                             // pin the result here: without a use in this block hipcc sinks the whole
                             // epilogue to the first consumer (the next layer), out of the MFMA shadow
-                            if constexpr (SAVE != 3)
+                            if constexpr (SAVE != SV_PE)
                                 asm volatile("" : "+v"(oh[2 * (t - 1) + (i >> 2)]), "+v"(ol[2 * (t - 1) + (i >> 2)]));
                         }
                 }
@@ -511,7 +624,7 @@ __device__ __forceinline__ void layer16(Pipe& p, int nb1, int nb2, h16x8 (&bh)[N
         // slab n+1 landed (only the pieces of slab n+2 may still fly); every wave done with slab n.
         // SAVE: the activation stores issued during this slab (4 per tile that had a pending epilogue) are younger
         // than every piece of slab n+1 as well, so they may stay in flight too
-        const int n_st = (SAVE == 1 || SAVE == 2) ? 4 * (s == 0 ? TPS - 1 : TPS) : 0;
+        const int n_st = (sv_fwd(SAVE) || sv_bwd(SAVE)) ? 4 * (s == 0 ? TPS - 1 : TPS) : 0;
         tile_sync(nissue / 4 + n_st);
         p.ph = p.ph == RING - 1 ? 0 : p.ph + 1;
         p.bias_off += TPS * 128;
@@ -525,22 +638,32 @@ __device__ __forceinline__ void layer16(Pipe& p, int nb1, int nb2, h16x8 (&bh)[N
     } else {
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-            if constexpr (SAVE == 1) {
+            if constexpr (SAVE == SV_ACT) {
                 float x0, x1;
                 epi_pair_x<RELU>(pacc1, pacc2, i, oh[2 * (NT - 1) + (i >> 2)], ol[2 * (NT - 1) + (i >> 2)], x0, x1);
                 save_pair(*sc, bw, NT - 1, i, x0, x1);
-            } else if constexpr (SAVE == 2) {
+            } else if constexpr (SAVE == SV_ACT_H) {
+                float x0, x1;
+                epi_pair_x<RELU>(pacc1, pacc2, i, oh[2 * (NT - 1) + (i >> 2)], ol[2 * (NT - 1) + (i >> 2)], x0, x1);
+                push_bit(bw[(NT - 1) >> 1], x0);
+                push_bit(bw[(NT - 1) >> 1], x1);
+                if (i & 1) store_frag_h(rowh, cxh, NT - 1, i, oh[2 * (NT - 1) + (i >> 2)]);
+            } else if constexpr (SAVE == SV_DZ) {
                 float x0, x1;
                 epi_pair_m(pacc1, pacc2, i, sc->mask[(NT - 1) >> 1] >> (16 * ((NT - 1) & 1)), oh[2 * (NT - 1) + (i >> 2)],
                            ol[2 * (NT - 1) + (i >> 2)], x0, x1);
                 save_pair_b(*sc, NT - 1, i, x0, x1);
-            } else if constexpr (SAVE == 3) {
+            } else if constexpr (SAVE == SV_DZ_H) {
+                const h16x2 hh = epi_pair_mh(pacc1, pacc2, i, sc->mask[(NT - 1) >> 1] >> (16 * (1 - ((NT - 1) & 1))),
+                                             oh[2 * (NT - 1) + (i >> 2)], ol[2 * (NT - 1) + (i >> 2)]);
+                store_pair_h(rowh, cxh, svu, NT - 1, i, hh);
+            } else if constexpr (SAVE == SV_PE) {
                 sc->fout[16 * (NT - 1) + 2 * i] = fmaf(pacc2[2 * i], LO_INV, pacc1[2 * i]);
                 sc->fout[16 * (NT - 1) + 2 * i + 1] = fmaf(pacc2[2 * i + 1], LO_INV, pacc1[2 * i + 1]);
             } else
             epi_pair<RELU>(pacc1, pacc2, i, oh[2 * (NT - 1) + (i >> 2)], ol[2 * (NT - 1) + (i >> 2)]);
         }
-        if constexpr (SAVE == 1) {
+        if constexpr (sv_fwd(SAVE)) {
 #pragma unroll
             for (int i = 0; i < (NT + 1) / 2; ++i) sc->bits[i] = bw[i];
         }
@@ -723,8 +846,9 @@ __device__ __forceinline__ void stash_pe(const Pipe& p, int ks, const float (&v)
 
 // K3, f16x3.  grid = ceil(P / 128) workgroups of 4 waves x 32 samples; LDS = 160 KiB.
 // SAVE (training forward): also writes pe_out [P,63], acts [8][P][256] (fp32 post-ReLU values, as combined in the
-// epilogue) and relu_bits [8][P][8] like canonical_f32_kernel<true>; no sparse form.
-template <bool SAVE>
+// epilogue) and relu_bits [8][P][8] like canonical_f32_kernel<true>; no sparse form.  SAVE == SV_ACT_H: acts and
+// pe_out are f16 matrices ([8][P][256], [P][64] with column 63 zero) for hnrf_mlp_dw_h.
+template <int SAVE>
 __global__ __launch_bounds__(256) void canonical_f16x3_kernel(const float* __restrict__ xyz,
                                                               const char* __restrict__ packed, int64_t P,
                                                               float4* __restrict__ raw, const int* __restrict__ idx,
@@ -761,45 +885,52 @@ __global__ __launch_bounds__(256) void canonical_f16x3_kernel(const float* __res
         // lanes past P hold a copy of sample P-1 and (re)write its rows: same values, and every wave issues the
         // same number of stores (see SaveCtx)
         sc.row = acts + sidx * 256 + 4 * h;
+        sc.rowh = reinterpret_cast<_Float16*>(acts) + (slot >> 5) * (256 * 32) + h * 128;                        // blocked
+        sc.cx = (lane & 31) ^ (4 * h);
         sc.bits = relu_bits + sidx * 8 + 4 * h;
 #pragma unroll
         for (int a = 0; a < 32; ++a) {
             const int col = pe_col16(PE16_CANONICAL, a, h);
-            if (col >= 0) pe_out[sidx * 63 + col] = pev[a];
+            if constexpr (SAVE == SV_ACT_H) reinterpret_cast<_Float16*>(pe_out)[sidx * 64 + (col >= 0 ? col : 63)] = (_Float16)(col >= 0 ? pev[a] : 0.f);
+            else if (col >= 0) pe_out[sidx * 63 + col] = pev[a];
         }
     }
     const int64_t act_stride = P * 256, bit_stride = P * 8;
+    const int64_t acth_stride = (int64_t)gridDim.x * 128 * 256;     // blocked f16 layers are padded to whole workgroups
     tile_sync(0);
 
     h16x8 hA_h[16], hA_l[16], hB_h[16], hB_l[16];
     float last[16];
     f32x16 pend1, pend2;                          // inference: last-tile epilogues travel into the next layer
-    constexpr bool DF = !SAVE;
-    layer16<8, 4, 4, 0, true, SAVE ? 1 : 0, false, DF>(p, CNL16_NB_MID, CNL16_NB_MID, hB_h, hB_l, hA_h, hA_l, last, &sc, &pend1, &pend2);   // (hB unused: NKB = 0)
-    if constexpr (SAVE) { sc.row += act_stride; sc.bits += bit_stride; }
+    constexpr bool DF = SAVE == SV_NONE;
+    layer16<8, 4, 4, 0, true, SAVE, false, DF>(p, CNL16_NB_MID, CNL16_NB_MID, hB_h, hB_l, hA_h, hA_l, last, &sc, &pend1, &pend2);   // (hB unused: NKB = 0)
+    if constexpr (SAVE) { sc.row += act_stride; sc.rowh += acth_stride; sc.bits += bit_stride; }
 #pragma unroll 1
     for (int l = 1; l <= 4; ++l) {
         const int nb = l == 4 ? CNL16_NB_L5 : CNL16_NB_MID;
-        layer16<8, 1, 0, 16, true, SAVE ? 1 : 0, DF, DF>(p, nb, nb, hA_h, hA_l, hB_h, hB_l, last, &sc, &pend1, &pend2);
-        if constexpr (SAVE) { sc.row += act_stride; sc.bits += bit_stride; }
+        layer16<8, 1, 0, 16, true, SAVE, DF, DF>(p, nb, nb, hA_h, hA_l, hB_h, hB_l, last, &sc, &pend1, &pend2);
+        if constexpr (SAVE) { sc.row += act_stride; sc.rowh += acth_stride; sc.bits += bit_stride; }
 #pragma unroll
         for (int i = 0; i < 16; ++i) { hA_h[i] = hB_h[i]; hA_l[i] = hB_l[i]; }
     }
-    layer16<8, 1, 4, 16, true, SAVE ? 1 : 0, DF, DF>(p, CNL16_NB_MID, CNL16_NB_MID, hA_h, hA_l, hB_h, hB_l, last, &sc, &pend1, &pend2);   // skip layer
-    if constexpr (SAVE) { sc.row += act_stride; sc.bits += bit_stride; }
+    layer16<8, 1, 4, 16, true, SAVE, DF, DF>(p, CNL16_NB_MID, CNL16_NB_MID, hA_h, hA_l, hB_h, hB_l, last, &sc, &pend1, &pend2);   // skip layer
+    if constexpr (SAVE) { sc.row += act_stride; sc.rowh += acth_stride; sc.bits += bit_stride; }
 #pragma unroll
     for (int i = 0; i < 16; ++i) { hA_h[i] = hB_h[i]; hA_l[i] = hB_l[i]; }
 #pragma unroll 1
     for (int l = 6; l <= 7; ++l) {
-        layer16<8, 1, 0, 16, true, SAVE ? 1 : 0, DF, DF>(p, CNL16_NB_MID, l == 7 ? 0 : CNL16_NB_MID, hA_h, hA_l, hB_h, hB_l, last, &sc, &pend1, &pend2);
-        if constexpr (SAVE) { sc.row += act_stride; sc.bits += bit_stride; }
+        layer16<8, 1, 0, 16, true, SAVE, DF, DF>(p, CNL16_NB_MID, l == 7 ? 0 : CNL16_NB_MID, hA_h, hA_l, hB_h, hB_l, last, &sc, &pend1, &pend2);
+        if constexpr (SAVE) { sc.row += act_stride; sc.rowh += acth_stride; sc.bits += bit_stride; }
 #pragma unroll
         for (int i = 0; i < 16; ++i) { hA_h[i] = hB_h[i]; hA_l[i] = hB_l[i]; }
     }
     h16x8 dh[2], dl[2];
     layer16<1, 1, 0, 16, false, 0, DF, false>(p, 0, 0, hA_h, hA_l, dh, dl, last, nullptr, &pend1, &pend2);
-    const float* ob = reinterpret_cast<const float*>(packed + CNL16_BIAS + CNL16_BIAS_LDS);   // head bias: scalar loads
-    if (h == 0 && slot < P) raw[sample] = make_float4(last[0] + ob[0], last[1] + ob[1], last[2] + ob[2], last[3] + ob[3]);
+    // head bias and the head's power-of-two descale (pack_layer16_kernel, head_scale): scalar loads
+    const float* ob = reinterpret_cast<const float*>(packed + CNL16_BIAS + CNL16_BIAS_LDS);
+    const float hs = ob[8];
+    if (h == 0 && slot < P)
+        raw[sample] = make_float4(fmaf(last[0], hs, ob[0]), fmaf(last[1], hs, ob[1]), fmaf(last[2], hs, ob[2]), fmaf(last[3], hs, ob[3]));
 #ifdef HNRF_STAMP
     if (threadIdx.x == 0 && blockIdx.x < 4096) {   // stamps leave through a buffer nothing else reads
         const unsigned long long te = __builtin_readcyclecounter();
@@ -809,8 +940,9 @@ __global__ __launch_bounds__(256) void canonical_f16x3_kernel(const float* __res
 #endif
 }
 
-// K2, f16x3 (width 128: 4 tiles, 8 k-steps).  SAVE: pe_out [P,36], acts [6][P][128], relu_bits [6][P][4].
-template <bool SAVE>
+// K2, f16x3 (width 128: 4 tiles, 8 k-steps).  SAVE: pe_out [P,36], acts [6][P][128], relu_bits [6][P][4];
+// SV_ACT_H: f16 acts and an f16 pe_out [P][64] (columns 36..63 zero).
+template <int SAVE>
 __global__ __launch_bounds__(256) void nonrigid_f16x3_kernel(const float* __restrict__ x_skel,
                                                              const float* __restrict__ hann_w,
                                                              const char* __restrict__ packed, int64_t P,
@@ -847,34 +979,46 @@ __global__ __launch_bounds__(256) void nonrigid_f16x3_kernel(const float* __rest
     SaveCtx sc;
     if constexpr (SAVE) {
         sc.row = acts + sidx * 128 + 4 * h;
+        sc.rowh = reinterpret_cast<_Float16*>(acts) + (slot >> 5) * (128 * 32) + h * 128;                        // blocked
+        sc.cx = (lane & 31) ^ (4 * h);
         sc.bits = relu_bits + sidx * 4 + 2 * h;
+        if constexpr (SAVE == SV_ACT_H) {
+            _Float16* ph = reinterpret_cast<_Float16*>(pe_out) + sidx * 64;
 #pragma unroll
-        for (int a = 0; a < 18; ++a) pe_out[sidx * 36 + pe_col16(PE16_NONRIGID, a, h)] = pev[a];
+            for (int a = 0; a < 18; ++a) ph[pe_col16(PE16_NONRIGID, a, h)] = (_Float16)pev[a];
+#pragma unroll
+            for (int a = 18; a < 32; ++a) ph[36 + 2 * (a - 18) + h] = (_Float16)0.f;
+        } else {
+#pragma unroll
+            for (int a = 0; a < 18; ++a) pe_out[sidx * 36 + pe_col16(PE16_NONRIGID, a, h)] = pev[a];
+        }
     }
     const int64_t act_stride = P * 128, bit_stride = P * 4;
+    const int64_t acth_stride = (int64_t)gridDim.x * 128 * 128;
     tile_sync(0);
 
     h16x8 hA_h[8], hA_l[8], hB_h[8], hB_l[8];
     float last[16];
-    layer16<4, 4, 4, 0, true, SAVE ? 1 : 0>(p, 0 /*already in flight*/, 2 * NR16_NB_MID, hB_h, hB_l, hA_h, hA_l, last, &sc);
-    if constexpr (SAVE) { sc.row += act_stride; sc.bits += bit_stride; }
+    layer16<4, 4, 4, 0, true, SAVE>(p, 0 /*already in flight*/, 2 * NR16_NB_MID, hB_h, hB_l, hA_h, hA_l, last, &sc);
+    if constexpr (SAVE) { sc.row += act_stride; sc.rowh += acth_stride; sc.bits += bit_stride; }
 #pragma unroll 1
     for (int l = 1; l <= 3; ++l) {
         // 128-wide tiles have only 8 k-steps: two tiles per slab halve the barriers per MFMA
         const int nb = l == 3 ? NR16_NB_L4 : 2 * NR16_NB_MID;
-        layer16<4, 2, 0, 8, true, SAVE ? 1 : 0>(p, nb, nb, hA_h, hA_l, hB_h, hB_l, last, &sc);
-        if constexpr (SAVE) { sc.row += act_stride; sc.bits += bit_stride; }
+        layer16<4, 2, 0, 8, true, SAVE>(p, nb, nb, hA_h, hA_l, hB_h, hB_l, last, &sc);
+        if constexpr (SAVE) { sc.row += act_stride; sc.rowh += acth_stride; sc.bits += bit_stride; }
 #pragma unroll
         for (int i = 0; i < 8; ++i) { hA_h[i] = hB_h[i]; hA_l[i] = hB_l[i]; }
     }
-    layer16<4, 1, 4, 8, true, SAVE ? 1 : 0>(p, 2 * NR16_NB_MID, 2 * NR16_NB_MID, hA_h, hA_l, hB_h, hB_l, last, &sc);    // skip layer
-    if constexpr (SAVE) { sc.row += act_stride; sc.bits += bit_stride; }
-    layer16<4, 2, 0, 8, true, SAVE ? 1 : 0>(p, NR16_NB_MID, 0, hB_h, hB_l, hA_h, hA_l, last, &sc);
+    layer16<4, 1, 4, 8, true, SAVE>(p, 2 * NR16_NB_MID, 2 * NR16_NB_MID, hA_h, hA_l, hB_h, hB_l, last, &sc);    // skip layer
+    if constexpr (SAVE) { sc.row += act_stride; sc.rowh += acth_stride; sc.bits += bit_stride; }
+    layer16<4, 2, 0, 8, true, SAVE>(p, NR16_NB_MID, 0, hB_h, hB_l, hA_h, hA_l, last, &sc);
     h16x8 dh[2], dl[2];
     layer16<1, 1, 0, 8, false>(p, 0, 0, hA_h, hA_l, dh, dl, last);
     const float* ob = reinterpret_cast<const float*>(packed + NR16_BIAS + NR16_BIAS_LDS);
+    const float hs = ob[8];                                     // head descale (pack_layer16_kernel, head_scale)
     if (h == 0 && slot < P) {
-        const float o0 = last[0] + ob[0], o1 = last[1] + ob[1], o2 = last[2] + ob[2];
+        const float o0 = fmaf(last[0], hs, ob[0]), o1 = fmaf(last[1], hs, ob[1]), o2 = fmaf(last[2], hs, ob[2]);
         xyz[sample * 3 + 0] = x[0] + o0;
         xyz[sample * 3 + 1] = x[1] + o1;
         xyz[sample * 3 + 2] = x[2] + o2;
@@ -960,10 +1104,11 @@ __global__ __launch_bounds__(256) void nonrigid_f16x3_x2_kernel(const float* __r
     h16x8 dh[2][2], dl[2][2];
     layer16x2<1, 1, 0, 8, false>(p, SPW, 0, 0, hA_h, hA_l, dh, dl, last);
     const float* ob = reinterpret_cast<const float*>(packed + NR16_BIAS + NR16_BIAS_LDS);
+    const float hs = ob[8];
 #pragma unroll
     for (int g = 0; g < 2; ++g) {
         if (h == 0 && live[g]) {
-            const float o0 = last[g][0] + ob[0], o1 = last[g][1] + ob[1], o2 = last[g][2] + ob[2];
+            const float o0 = fmaf(last[g][0], hs, ob[0]), o1 = fmaf(last[g][1], hs, ob[1]), o2 = fmaf(last[g][2], hs, ob[2]);
             xyz[sidx[g] * 3 + 0] = x[g][0] + o0;
             xyz[sidx[g] * 3 + 1] = x[g][1] + o1;
             xyz[sidx[g] * 3 + 2] = x[g][2] + o2;
@@ -992,7 +1137,27 @@ struct PackBwd16 {
     int col0;
     int head;              // 1: K = the n_out (<= 4) head outputs, elements 0..3 of lane half 0 of k-step 0
     int64_t off;           // byte offset of the stage's first slab
+    const int* kexp;       // device: this layer's layer_exponent (weights are stored x 2^k)
 };
+
+// exponent table of a whole MLP: block l reduces max |W_l| and writes layer_exponent of it
+struct LayerSet {
+    const float* w[9];
+    int n[9];
+};
+__global__ __launch_bounds__(256) void layer_exp_kernel(LayerSet ls, int* __restrict__ out) {
+    __shared__ float red[256];
+    const float* W = ls.w[blockIdx.x];
+    float m = 0.f;
+    for (int e = threadIdx.x; e < ls.n[blockIdx.x]; e += 256) m = fmaxf(m, fabsf(W[e]));
+    red[threadIdx.x] = m;
+    __syncthreads();
+    for (int st = 128; st >= 1; st >>= 1) {
+        if ((int)threadIdx.x < st) red[threadIdx.x] = fmaxf(red[threadIdx.x], red[threadIdx.x + st]);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[blockIdx.x] = layer_exponent(red[0]);
+}
 
 __global__ void pack_bwd16_kernel(PackBwd16 d, char* __restrict__ packed) {
     const int slab_units = 2 * d.NK * 256;
@@ -1007,6 +1172,7 @@ __global__ void pack_bwd16_kernel(PackBwd16 d, char* __restrict__ packed) {
     const int j0 = (u & 3) * 2;
     const int h = lane >> 5;
     const int rho = 32 * t + (lane & 31);
+    const int kexp = *d.kexp;
     int col;
     if (d.row_kind == PE16_NONE) {
         col = d.col0 + rho;
@@ -1021,7 +1187,7 @@ __global__ void pack_bwd16_kernel(PackBwd16 d, char* __restrict__ packed) {
         const int j = j0 + e;
         const int o = d.head ? ((ks == 0 && h == 0 && j < d.n_out) ? j : -1) : hid_feat16(ks, j, h);
         float w = 0.f;
-        if (o >= 0 && o < d.n_out && col >= 0 && col < d.n_in) w = d.W[(int64_t)o * d.n_in + col];
+        if (o >= 0 && o < d.n_out && col >= 0 && col < d.n_in) w = ldexpf(d.W[(int64_t)o * d.n_in + col], kexp);
         const _Float16 hi = (_Float16)w;
         const _Float16 lo = (_Float16)((w - (float)hi) * LO_SCALE);
         outv[e] = part ? lo : hi;
@@ -1038,7 +1204,7 @@ constexpr int64_t CB16_L7 = CB16_HEAD + 16 * KB;
 constexpr int64_t CB16_L5P = CB16_L7 + 3 * CB16_FULL;
 constexpr int64_t CB16_L4 = CB16_L5P + CB16_PE;
 constexpr int64_t CB16_L0P = CB16_L4 + 4 * CB16_FULL;
-constexpr int64_t CB16_BYTES = CB16_L0P + CB16_PE;
+constexpr int64_t CB16_BYTES = CB16_L0P + CB16_PE;            // followed by int kexp[9] (layer_exp_kernel), 256 bytes
 
 __device__ __forceinline__ void chain_amax(SaveCtx& sc, float* __restrict__ slot) {
     float m = sc.amax;
@@ -1048,6 +1214,9 @@ __device__ __forceinline__ void chain_amax(SaveCtx& sc, float* __restrict__ slot
     sc.amax = 0.f;
 }
 
+// HALF: dZ is an f16 matrix holding the chain's SCALED values (dz_scale[l] = the power of two dZ_l was multiplied by, for
+// hnrf_mlp_dw_h); otherwise fp32, un-scaled, with the per-layer maxima in dz_amax.
+template <bool HALF>
 __global__ __launch_bounds__(256) void canonical_bwd16_kernel(const float* __restrict__ xyz,
                                                               const float4* __restrict__ d_raw,
                                                               const uint32_t* __restrict__ relu_bits,
@@ -1056,6 +1225,7 @@ __global__ __launch_bounds__(256) void canonical_bwd16_kernel(const float* __res
                                                               float* __restrict__ dZ, float* __restrict__ d_xyz,
                                                               float* __restrict__ dz_amax) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int SV = HALF ? SV_DZ_H : SV_DZ;
     // slabs: head (16 blocks), then 32-block slabs; the first THREE are put in flight here (the head stage has
     // only 8 k-steps to issue DMA pieces from, one short of a 32-block slab)
     Pipe p = pipe_start(packed, 0, CNL16_BIAS_LDS, CNL16_SLAB, 16, 32, smem);
@@ -1065,28 +1235,43 @@ __global__ __launch_bounds__(256) void canonical_bwd16_kernel(const float* __res
     const int64_t slot = ((int64_t)blockIdx.x * 4 + p.wave) * 32 + (lane & 31);
     const int64_t sample = slot < P ? slot : P - 1;            // lanes past P repeat sample P-1 (same values stored)
     const int64_t stride = P * 256, bstride = P * 8;
+    const int* kt = reinterpret_cast<const int*>(packed + CB16_BYTES);      // weights of layer l are stored x 2^kt[l]
 
+    // non-finite incoming gradient (an overflowed loss): the scale would be undefined -- gradients of zero scale come
+    // out as NaN everywhere instead of silently wrong (and the caller's finite check sees them)
     int ex = 0;
     const float am_in = *d_raw_amax;
     if (am_in > 0.f) (void)frexpf(am_in, &ex);
-    const float scale = ldexpf(1.0f, 2 - ex);
-    const float4 g = d_raw[sample];
+    const float scale = (am_in == am_in && am_in < 3.0e38f) ? ldexpf(1.0f, 2 - ex) : __builtin_nanf("");
+    // HALF: lanes past P must leave zeros in the blocked dZ (the weight-gradient kernel reads whole blocks): a zero
+    // incoming gradient does that for every stage
+    const float4 g = (HALF && slot >= P) ? float4{0.f, 0.f, 0.f, 0.f} : d_raw[sample];
     {
         const float v[8] = {h ? 0.f : g.x * scale, h ? 0.f : g.y * scale, h ? 0.f : g.z * scale, h ? 0.f : g.w * scale,
                             0.f, 0.f, 0.f, 0.f};
         stash_pe(p, 0, v);
     }
     SaveCtx sc;
-    sc.descale = ldexpf(1.0f, ex - 2);
+    float S = scale * ldexpf(1.0f, kt[8]);                      // scale of the stage being computed (dZ7 = W8^T d_raw)
+    sc.descale = 1.0f / S;
     sc.amax = 0.f;
     sc.row = dZ + 7 * stride + sample * 256 + 4 * h;
+    const int64_t strideh = (int64_t)gridDim.x * 128 * 256;     // blocked f16 layers, padded to whole workgroups
+    sc.rowh = reinterpret_cast<_Float16*>(dZ) + 7 * strideh + (slot >> 5) * (256 * 32) + h * 128;
+    sc.cx = (lane & 31) ^ (4 * h);
     const uint32_t* mrow = relu_bits + 7 * bstride + sample * 8 + 4 * h;
     float* am = dz_amax ? dz_amax + 7 * HNRF_AMAX_SLOTS + (blockIdx.x % HNRF_AMAX_SLOTS) : nullptr;
-    auto next_stage = [&]() {                                    // after a stored stage: publish its maximum, step a layer down
-        chain_amax(sc, am);
+    float* sout = (HALF && dz_amax && blockIdx.x == 0 && threadIdx.x == 0) ? dz_amax + 7 : nullptr;   // HALF: dz_amax = scale[8]
+    if (sout) *sout = S;
+    auto next_stage = [&](int w_next) {                          // after a stored stage: step a layer down; the next stage
+        if constexpr (!HALF) chain_amax(sc, am);                 // multiplies by the weights of layer w_next
         sc.row -= stride;
+        sc.rowh -= strideh;
         mrow -= bstride;
         if (am) am -= HNRF_AMAX_SLOTS;
+        S *= ldexpf(1.0f, kt[w_next]);
+        sc.descale = 1.0f / S;
+        if (sout && w_next > 0) { --sout; *sout = S; }           // (w_next = 0: the scale of layer 0's d PE, not a dZ)
     };
     auto load_mask = [&]() {
         const uint4 m = *reinterpret_cast<const uint4*>(mrow);
@@ -1098,52 +1283,50 @@ __global__ __launch_bounds__(256) void canonical_bwd16_kernel(const float* __res
     h16x8 dh[4], dl[4];
     float last[16];
     load_mask();
-    layer16<8, 8, 1, 0, false, 2>(p, 0, 0, hB_h, hB_l, hA_h, hA_l, last, &sc);                 // dZ7 (hB unused: NKB = 0)
-    next_stage();
+    layer16<8, 8, 1, 0, false, SV>(p, 0, 0, hB_h, hB_l, hA_h, hA_l, last, &sc);                // dZ7 (hB unused: NKB = 0)
+    next_stage(7);
 #pragma unroll 1
     for (int m = 6; m >= 5; --m) {                                                             // dZ6, dZ5
         load_mask();
-        layer16<8, 1, 0, 16, false, 2>(p, 32, 32, hA_h, hA_l, hB_h, hB_l, last, &sc);
-        next_stage();
+        layer16<8, 1, 0, 16, false, SV>(p, 32, 32, hA_h, hA_l, hB_h, hB_l, last, &sc);
+        next_stage(m);
 #pragma unroll
         for (int i = 0; i < 16; ++i) { hA_h[i] = hB_h[i]; hA_l[i] = hB_l[i]; }
     }
     load_mask();
-    layer16<8, 1, 0, 16, false, 2>(p, 32, 32, hA_h, hA_l, hB_h, hB_l, last, &sc);             // skip layer: dZ4 ...
-    next_stage();
-    layer16<2, 1, 0, 16, false, 3>(p, 32, 32, hA_h, hA_l, dh, dl, last, &sc);                 // ... and its d PE
-    float dpe[32];
-#pragma unroll
-    for (int j = 0; j < 32; ++j) dpe[j] = sc.fout[j];
-#pragma unroll
-    for (int i = 0; i < 16; ++i) { hA_h[i] = hB_h[i]; hA_l[i] = hB_l[i]; }
-#pragma unroll 1
-    for (int m = 3; m >= 0; --m) {                                                             // dZ3 .. dZ0
-        load_mask();
-        layer16<8, 1, 0, 16, false, 2>(p, 32, 32, hA_h, hA_l, hB_h, hB_l, last, &sc);
-        next_stage();
-#pragma unroll
-        for (int i = 0; i < 16; ++i) { hA_h[i] = hB_h[i]; hA_l[i] = hB_l[i]; }
-    }
-    layer16<2, 1, 0, 16, false, 3>(p, 0, 0, hA_h, hA_l, dh, dl, last, &sc);                   // layer 0's d PE
-#pragma unroll
-    for (int j = 0; j < 32; ++j) dpe[j] = (dpe[j] + sc.fout[j]) * sc.descale;
-
-    // PE backward on the lane's own sample: argument a = 3 k + axis, half 0 = sin, half 1 = cos
+    layer16<8, 1, 0, 16, false, SV>(p, 32, 32, hA_h, hA_l, hB_h, hB_l, last, &sc);            // skip layer: dZ4 ...
+    const float inv_skip = sc.descale;                                                         // (W5^T: hidden and PE rows share kt[5])
+    next_stage(4);
+    layer16<2, 1, 0, 16, false, SV_PE>(p, 32, 32, hA_h, hA_l, dh, dl, last, &sc);             // ... and its d PE
+    // PE backward on the lane's own sample (argument a = 3 k + axis, half 0 = sin, half 1 = cos), folded into d_xyz right
+    // here: carrying the 32 d PE values through the four stages below would cost 32 registers of a kernel that has none
     const float x[3] = {xyz[sample * 3 + 0], xyz[sample * 3 + 1], xyz[sample * 3 + 2]};
     float dx[3] = {0.f, 0.f, 0.f};
-    {
+    auto pe_backward = [&](float sc_inv) {
         OctavePhase ph[3] = {OctavePhase(x[0]), OctavePhase(x[1]), OctavePhase(x[2])};
 #pragma unroll
         for (int a = 0; a < 30; ++a) {
             float sv, cv;
             ph[a % 3].next(sv, cv);
-            const float f = (float)(1 << (a / 3));
-            dx[a % 3] += f * (h ? -sv : cv) * dpe[a];
+            const float f = (float)(1 << (a / 3)) * sc_inv;
+            dx[a % 3] += f * (h ? -sv : cv) * sc.fout[a];
         }
+        dx[h ? 1 : 0] += sc.fout[30] * sc_inv;
+        if (h == 0) dx[2] += sc.fout[31] * sc_inv;
+    };
+    pe_backward(inv_skip);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { hA_h[i] = hB_h[i]; hA_l[i] = hB_l[i]; }
+#pragma unroll 1
+    for (int m = 3; m >= 0; --m) {                                                             // dZ3 .. dZ0
+        load_mask();
+        layer16<8, 1, 0, 16, false, SV>(p, 32, 32, hA_h, hA_l, hB_h, hB_l, last, &sc);
+        next_stage(m);                                                                         // (m = 0: scale of layer 0's d PE)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { hA_h[i] = hB_h[i]; hA_l[i] = hB_l[i]; }
     }
-    dx[h ? 1 : 0] += dpe[30];
-    if (h == 0) dx[2] += dpe[31];
+    layer16<2, 1, 0, 16, false, SV_PE>(p, 0, 0, hA_h, hA_l, dh, dl, last, &sc);               // layer 0's d PE
+    pe_backward(sc.descale);
 #pragma unroll
     for (int a = 0; a < 3; ++a) dx[a] += __shfl_xor(dx[a], 32, 64);
     if (h == 0 && slot < P) {
@@ -1162,9 +1345,11 @@ constexpr int64_t NB16_L5 = NB16_HEAD + 8 * KB;
 constexpr int64_t NB16_L4P = NB16_L5 + 2 * NB16_FULL;
 constexpr int64_t NB16_L3 = NB16_L4P + NB16_PE;
 constexpr int64_t NB16_L0P = NB16_L3 + 3 * NB16_FULL;
-constexpr int64_t NB16_BYTES = NB16_L0P + NB16_PE;
+constexpr int64_t NB16_BYTES = NB16_L0P + NB16_PE;            // followed by int kexp[7], 256 bytes
 
 // Non-rigid MLP, split-f16 (xyz = x_skel + offset): d_x_skel = d_xyz + J_offset^T d_xyz, dZ [6][P][128].
+// HALF: see canonical_bwd16_kernel.
+template <bool HALF>
 __global__ __launch_bounds__(256) void nonrigid_bwd16_kernel(const float* __restrict__ x_skel,
                                                              const float* __restrict__ hann_w,
                                                              const float* __restrict__ d_xyz,
@@ -1174,6 +1359,7 @@ __global__ __launch_bounds__(256) void nonrigid_bwd16_kernel(const float* __rest
                                                              float* __restrict__ dZ, float* __restrict__ d_x_skel,
                                                              float* __restrict__ dz_amax) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int SV = HALF ? SV_DZ_H : SV_DZ;
     Pipe p = pipe_start(packed, 0, NR16_BIAS_LDS, NR16_SLAB, 8, 32, smem);
     slab_issue(p.gi, p.lds_base + p.ring_off + 2 * NR16_SLAB, 32, p.wave);      // third slab: see canonical_bwd16_kernel
     p.gi += 32 * 1024;
@@ -1181,28 +1367,40 @@ __global__ __launch_bounds__(256) void nonrigid_bwd16_kernel(const float* __rest
     const int64_t slot = ((int64_t)blockIdx.x * 4 + p.wave) * 32 + (lane & 31);
     const int64_t sample = slot < P ? slot : P - 1;
     const int64_t stride = P * 128, bstride = P * 4;
+    const int* kt = reinterpret_cast<const int*>(packed + NB16_BYTES);
 
     int ex = 0;
     const float am_in = *d_xyz_amax;
     if (am_in > 0.f) (void)frexpf(am_in, &ex);
-    const float scale = ldexpf(1.0f, 2 - ex);
-    const float g[3] = {d_xyz[sample * 3 + 0], d_xyz[sample * 3 + 1], d_xyz[sample * 3 + 2]};
+    const float scale = (am_in == am_in && am_in < 3.0e38f) ? ldexpf(1.0f, 2 - ex) : __builtin_nanf("");
+    const bool dead = HALF && slot >= P;                        // see canonical_bwd16_kernel
+    const float g[3] = {dead ? 0.f : d_xyz[sample * 3 + 0], dead ? 0.f : d_xyz[sample * 3 + 1], dead ? 0.f : d_xyz[sample * 3 + 2]};
     {
         const float v[8] = {h ? 0.f : g[0] * scale, h ? 0.f : g[1] * scale, h ? 0.f : g[2] * scale, 0.f, 0.f, 0.f, 0.f, 0.f};
         stash_pe(p, 0, v);
     }
     SaveCtx sc;
-    sc.descale = ldexpf(1.0f, ex - 2);
+    float S = scale * ldexpf(1.0f, kt[6]);                       // dZ5 = W6^T d_xyz
+    sc.descale = 1.0f / S;
     sc.amax = 0.f;
     sc.mask[2] = sc.mask[3] = 0u;
     sc.row = dZ + 5 * stride + sample * 128 + 4 * h;
+    const int64_t strideh = (int64_t)gridDim.x * 128 * 128;
+    sc.rowh = reinterpret_cast<_Float16*>(dZ) + 5 * strideh + (slot >> 5) * (128 * 32) + h * 128;
+    sc.cx = (lane & 31) ^ (4 * h);
     const uint32_t* mrow = relu_bits + 5 * bstride + sample * 4 + 2 * h;
     float* am = dz_amax ? dz_amax + 5 * HNRF_AMAX_SLOTS + (blockIdx.x % HNRF_AMAX_SLOTS) : nullptr;
-    auto next_stage = [&]() {
-        chain_amax(sc, am);
+    float* sout = (HALF && dz_amax && blockIdx.x == 0 && threadIdx.x == 0) ? dz_amax + 5 : nullptr;   // HALF: dz_amax = scale[6]
+    if (sout) *sout = S;
+    auto next_stage = [&](int w_next) {
+        if constexpr (!HALF) chain_amax(sc, am);
         sc.row -= stride;
+        sc.rowh -= strideh;
         mrow -= bstride;
         if (am) am -= HNRF_AMAX_SLOTS;
+        S *= ldexpf(1.0f, kt[w_next]);
+        sc.descale = 1.0f / S;
+        if (sout && w_next > 0) { --sout; *sout = S; }
     };
     auto load_mask = [&]() {
         const uint2 m = *reinterpret_cast<const uint2*>(mrow);
@@ -1214,32 +1412,33 @@ __global__ __launch_bounds__(256) void nonrigid_bwd16_kernel(const float* __rest
     h16x8 dh[4], dl[4];
     float last[16];
     load_mask();
-    layer16<4, 4, 1, 0, false, 2>(p, 0, 0, hB_h, hB_l, hA_h, hA_l, last, &sc);                // dZ5
-    next_stage();
+    layer16<4, 4, 1, 0, false, SV>(p, 0, 0, hB_h, hB_l, hA_h, hA_l, last, &sc);                // dZ5
+    next_stage(5);
     load_mask();
-    layer16<4, 2, 0, 8, false, 2>(p, 32, 32, hA_h, hA_l, hB_h, hB_l, last, &sc);             // dZ4 (the skip layer's)
-    next_stage();
+    layer16<4, 2, 0, 8, false, SV>(p, 32, 32, hA_h, hA_l, hB_h, hB_l, last, &sc);             // dZ4 (the skip layer's)
+    next_stage(4);
     load_mask();
-    layer16<4, 2, 0, 8, false, 2>(p, 32, 32, hB_h, hB_l, hA_h, hA_l, last, &sc);             // skip [h | PE]: dZ3 ...
-    next_stage();
-    layer16<2, 2, 0, 8, false, 3>(p, 32, 32, hB_h, hB_l, dh, dl, last, &sc);                 // ... and its d PE
+    layer16<4, 2, 0, 8, false, SV>(p, 32, 32, hB_h, hB_l, hA_h, hA_l, last, &sc);             // skip [h | PE]: dZ3 ...
+    const float inv_skip = sc.descale;                                                         // (W4^T: hidden and PE rows share kt[4])
+    next_stage(3);
+    layer16<2, 2, 0, 8, false, SV_PE>(p, 32, 32, hB_h, hB_l, dh, dl, last, &sc);              // ... and its d PE
     float dpe[18];
 #pragma unroll
-    for (int j = 0; j < 18; ++j) dpe[j] = sc.fout[j];
+    for (int j = 0; j < 18; ++j) dpe[j] = sc.fout[j] * inv_skip;
 #pragma unroll 1
     for (int m = 2; m >= 1; --m) {                                                            // dZ2, dZ1
         load_mask();
-        layer16<4, 2, 0, 8, false, 2>(p, 32, 32, hA_h, hA_l, hB_h, hB_l, last, &sc);
-        next_stage();
+        layer16<4, 2, 0, 8, false, SV>(p, 32, 32, hA_h, hA_l, hB_h, hB_l, last, &sc);
+        next_stage(m);
 #pragma unroll
         for (int i = 0; i < 8; ++i) { hA_h[i] = hB_h[i]; hA_l[i] = hB_l[i]; }
     }
     load_mask();
-    layer16<4, 2, 0, 8, false, 2>(p, 32, 0, hA_h, hA_l, hB_h, hB_l, last, &sc);              // dZ0
-    next_stage();
-    layer16<2, 2, 0, 8, false, 3>(p, 0, 0, hB_h, hB_l, dh, dl, last, &sc);                   // layer 0's d PE
+    layer16<4, 2, 0, 8, false, SV>(p, 32, 0, hA_h, hA_l, hB_h, hB_l, last, &sc);              // dZ0
+    next_stage(0);                                                                             // (scale of layer 0's d PE)
+    layer16<2, 2, 0, 8, false, SV_PE>(p, 0, 0, hB_h, hB_l, dh, dl, last, &sc);                // layer 0's d PE
 #pragma unroll
-    for (int j = 0; j < 18; ++j) dpe[j] = (dpe[j] + sc.fout[j]) * sc.descale;
+    for (int j = 0; j < 18; ++j) dpe[j] = fmaf(sc.fout[j], sc.descale, dpe[j]);
 
     const float x[3] = {x_skel[sample * 3 + 0], x_skel[sample * 3 + 1], x_skel[sample * 3 + 2]};
     float dx[3] = {0.f, 0.f, 0.f};
@@ -1278,21 +1477,21 @@ int canonical16_pack(const float* const* w, const float* const* b, void* packed,
         set_error("hnrf_canonical_pack: memset failed");
         return HNRF_E_LAUNCH;
     }
-    PackLayer16 d{w[0], b[0], 256, 63, 8, 4, 0, PE16_CANONICAL, 0, 0, 0, CNL16_L0, CNL16_BIAS};
+    PackLayer16 d{w[0], b[0], 256, 63, 8, 4, 0, PE16_CANONICAL, 0, 0, 0, CNL16_L0, CNL16_BIAS, 0};
     if ((rc = launch_pack16(d, nullptr, out, st))) return rc;
     for (int l = 1; l <= 4; ++l) {
         d = PackLayer16{w[l], b[l], 256, 256, 8, 0, 16, PE16_NONE, 0, 0, 0,
-                        CNL16_L1 + (l - 1) * 8 * CNL16_NB_MID * KB, CNL16_BIAS + l * 1024};
+                        CNL16_L1 + (l - 1) * 8 * CNL16_NB_MID * KB, CNL16_BIAS + l * 1024, 0};
         if ((rc = launch_pack16(d, nullptr, out, st))) return rc;
     }
-    d = PackLayer16{w[5], b[5], 256, 319, 8, 4, 16, PE16_CANONICAL, 0, 63, 0, CNL16_L5, CNL16_BIAS + 5 * 1024};
+    d = PackLayer16{w[5], b[5], 256, 319, 8, 4, 16, PE16_CANONICAL, 0, 63, 0, CNL16_L5, CNL16_BIAS + 5 * 1024, 0};
     if ((rc = launch_pack16(d, nullptr, out, st))) return rc;
     for (int l = 6; l <= 7; ++l) {
         d = PackLayer16{w[l], b[l], 256, 256, 8, 0, 16, PE16_NONE, 0, 0, 0,
-                        CNL16_L6 + (l - 6) * 8 * CNL16_NB_MID * KB, CNL16_BIAS + l * 1024};
+                        CNL16_L6 + (l - 6) * 8 * CNL16_NB_MID * KB, CNL16_BIAS + l * 1024, 0};
         if ((rc = launch_pack16(d, nullptr, out, st))) return rc;
     }
-    d = PackLayer16{w[8], b[8], 4, 256, 1, 0, 16, PE16_NONE, 0, 0, 0, CNL16_OUT, CNL16_BIAS + 8 * 1024};
+    d = PackLayer16{w[8], b[8], 4, 256, 1, 0, 16, PE16_NONE, 0, 0, 0, CNL16_OUT, CNL16_BIAS + 8 * 1024, 1};
     return launch_pack16(d, nullptr, out, st);
 }
 
@@ -1303,19 +1502,19 @@ int nonrigid16_pack(const float* const* w, const float* const* b, const float* c
         set_error("hnrf_nonrigid_pack: memset failed");
         return HNRF_E_LAUNCH;
     }
-    PackLayer16 d{w[0], b[0], 128, 105, 4, 4, 0, PE16_NONRIGID, 69, 0, 69, NR16_L0, NR16_BIAS};
+    PackLayer16 d{w[0], b[0], 128, 105, 4, 4, 0, PE16_NONRIGID, 69, 0, 69, NR16_L0, NR16_BIAS, 0};
     if ((rc = launch_pack16(d, cond, out, st))) return rc;
     for (int l = 1; l <= 3; ++l) {
         d = PackLayer16{w[l], b[l], 128, 128, 4, 0, 8, PE16_NONE, 0, 0, 0,
-                        NR16_L1 + (l - 1) * 4 * NR16_NB_MID * KB, NR16_BIAS + l * 512};
+                        NR16_L1 + (l - 1) * 4 * NR16_NB_MID * KB, NR16_BIAS + l * 512, 0};
         if ((rc = launch_pack16(d, cond, out, st))) return rc;
     }
     // W4 columns: [h(128) | PE36] (mlp_offset.py:81-82); our K order is [PE | h]
-    d = PackLayer16{w[4], b[4], 128, 164, 4, 4, 8, PE16_NONRIGID, 128, 0, 0, NR16_L4, NR16_BIAS + 4 * 512};
+    d = PackLayer16{w[4], b[4], 128, 164, 4, 4, 8, PE16_NONRIGID, 128, 0, 0, NR16_L4, NR16_BIAS + 4 * 512, 0};
     if ((rc = launch_pack16(d, cond, out, st))) return rc;
-    d = PackLayer16{w[5], b[5], 128, 128, 4, 0, 8, PE16_NONE, 0, 0, 0, NR16_L5, NR16_BIAS + 5 * 512};
+    d = PackLayer16{w[5], b[5], 128, 128, 4, 0, 8, PE16_NONE, 0, 0, 0, NR16_L5, NR16_BIAS + 5 * 512, 0};
     if ((rc = launch_pack16(d, cond, out, st))) return rc;
-    d = PackLayer16{w[6], b[6], 3, 128, 1, 0, 8, PE16_NONE, 0, 0, 0, NR16_OUT, NR16_BIAS + 6 * 512};
+    d = PackLayer16{w[6], b[6], 3, 128, 1, 0, 8, PE16_NONE, 0, 0, 0, NR16_OUT, NR16_BIAS + 6 * 512, 1};
     return launch_pack16(d, cond, out, st);
 }
 
@@ -1323,19 +1522,26 @@ int canonical16_fwd(const float* xyz, const void* packed, int64_t P, float* raw,
                     hipStream_t st) {
     constexpr int lds = CNL16_BIAS_LDS + PE_STASH + RING * CNL16_SLAB;
     static unsigned long long lds_done = 0;
-    if (int rc = reserve_lds((const void*)canonical_f16x3_kernel<false>, lds, lds_done, "hnrf_canonical_fwd (f16x3)")) return rc;
-    hipLaunchKernelGGL(canonical_f16x3_kernel<false>, dim3((unsigned)((P + 127) / 128)), dim3(256), lds, st, xyz,
+    if (int rc = reserve_lds((const void*)canonical_f16x3_kernel<SV_NONE>, lds, lds_done, "hnrf_canonical_fwd (f16x3)")) return rc;
+    hipLaunchKernelGGL(canonical_f16x3_kernel<SV_NONE>, dim3((unsigned)((P + 127) / 128)), dim3(256), lds, st, xyz,
                        (const char*)packed, P, (float4*)raw, idx, count, nullptr, nullptr, nullptr);
     return check_launch("hnrf_canonical_fwd (f16x3)");
 }
 
 int canonical16_fwd_train(const float* xyz, const void* packed, int64_t P, float* raw, float* pe_out, float* acts,
-                          uint32_t* relu_bits, hipStream_t st) {
+                          uint32_t* relu_bits, int half, hipStream_t st) {
     constexpr int lds = CNL16_BIAS_LDS + PE_STASH + RING * CNL16_SLAB;
-    static unsigned long long lds_done = 0;
-    if (int rc = reserve_lds((const void*)canonical_f16x3_kernel<true>, lds, lds_done, "hnrf_canonical_fwd_train (f16x3)")) return rc;
-    hipLaunchKernelGGL(canonical_f16x3_kernel<true>, dim3((unsigned)((P + 127) / 128)), dim3(256), lds, st, xyz,
-                       (const char*)packed, P, (float4*)raw, nullptr, nullptr, pe_out, acts, relu_bits);
+    static unsigned long long lds_done = 0, lds_done_h = 0;
+    const dim3 grid((unsigned)((P + 127) / 128));
+    if (half) {
+        if (int rc = reserve_lds((const void*)canonical_f16x3_kernel<SV_ACT_H>, lds, lds_done_h, "hnrf_canonical_fwd_train (f16x3, f16 operands)")) return rc;
+        hipLaunchKernelGGL(canonical_f16x3_kernel<SV_ACT_H>, grid, dim3(256), lds, st, xyz, (const char*)packed, P,
+                           (float4*)raw, nullptr, nullptr, pe_out, acts, relu_bits);
+    } else {
+        if (int rc = reserve_lds((const void*)canonical_f16x3_kernel<SV_ACT>, lds, lds_done, "hnrf_canonical_fwd_train (f16x3)")) return rc;
+        hipLaunchKernelGGL(canonical_f16x3_kernel<SV_ACT>, grid, dim3(256), lds, st, xyz, (const char*)packed, P,
+                           (float4*)raw, nullptr, nullptr, pe_out, acts, relu_bits);
+    }
     return check_launch("hnrf_canonical_fwd_train (f16x3)");
 }
 
@@ -1343,7 +1549,7 @@ int nonrigid16_fwd(const float* x_skel, const float* hann_w, const void* packed,
                    float* offsets, const int* idx, const int* count, hipStream_t st) {
     constexpr int lds = NR16_BIAS_LDS + PE_STASH + RING * NR16_SLAB;
     static unsigned long long lds_done = 0;
-    if (int rc = reserve_lds((const void*)nonrigid_f16x3_kernel<false>, lds, lds_done, "hnrf_nonrigid_fwd (f16x3)")) return rc;
+    if (int rc = reserve_lds((const void*)nonrigid_f16x3_kernel<SV_NONE>, lds, lds_done, "hnrf_nonrigid_fwd (f16x3)")) return rc;
     (void)lds;
     constexpr int lds2 = NR16_BIAS_LDS + NR16X2_STASH + RING * NR16X2_SLAB;
     static unsigned long long lds2_done = 0;
@@ -1354,72 +1560,107 @@ int nonrigid16_fwd(const float* x_skel, const float* hann_w, const void* packed,
 }
 
 int nonrigid16_fwd_train(const float* x_skel, const float* hann_w, const void* packed, int64_t P, float* xyz,
-                         float* offsets, float* pe_out, float* acts, uint32_t* relu_bits, hipStream_t st) {
+                         float* offsets, float* pe_out, float* acts, uint32_t* relu_bits, int half, hipStream_t st) {
     constexpr int lds = NR16_BIAS_LDS + PE_STASH + RING * NR16_SLAB;
-    static unsigned long long lds_done = 0;
-    if (int rc = reserve_lds((const void*)nonrigid_f16x3_kernel<true>, lds, lds_done, "hnrf_nonrigid_fwd_train (f16x3)")) return rc;
-    hipLaunchKernelGGL(nonrigid_f16x3_kernel<true>, dim3((unsigned)((P + 127) / 128)), dim3(256), lds, st, x_skel, hann_w,
-                       (const char*)packed, P, xyz, offsets, nullptr, nullptr, pe_out, acts, relu_bits);
+    static unsigned long long lds_done = 0, lds_done_h = 0;
+    const dim3 grid((unsigned)((P + 127) / 128));
+    if (half) {
+        if (int rc = reserve_lds((const void*)nonrigid_f16x3_kernel<SV_ACT_H>, lds, lds_done_h, "hnrf_nonrigid_fwd_train (f16x3, f16 operands)")) return rc;
+        hipLaunchKernelGGL(nonrigid_f16x3_kernel<SV_ACT_H>, grid, dim3(256), lds, st, x_skel, hann_w, (const char*)packed, P,
+                           xyz, offsets, nullptr, nullptr, pe_out, acts, relu_bits);
+    } else {
+        if (int rc = reserve_lds((const void*)nonrigid_f16x3_kernel<SV_ACT>, lds, lds_done, "hnrf_nonrigid_fwd_train (f16x3)")) return rc;
+        hipLaunchKernelGGL(nonrigid_f16x3_kernel<SV_ACT>, grid, dim3(256), lds, st, x_skel, hann_w, (const char*)packed, P,
+                           xyz, offsets, nullptr, nullptr, pe_out, acts, relu_bits);
+    }
     return check_launch("hnrf_nonrigid_fwd_train (f16x3)");
 }
 
-size_t canonical16_bwd_bytes() { return (size_t)CB16_BYTES; }
+size_t canonical16_bwd_bytes() { return (size_t)CB16_BYTES + 256; }
+
+static int launch_layer_exp(const float* const* w, const int* n, int count, int* out, hipStream_t st) {
+    LayerSet ls;
+    for (int i = 0; i < 9; ++i) { ls.w[i] = i < count ? w[i] : nullptr; ls.n[i] = i < count ? n[i] : 0; }
+    hipLaunchKernelGGL(layer_exp_kernel, dim3(count), dim3(256), 0, st, ls, out);
+    return check_launch("hnrf pack (layer exponents)");
+}
 
 int canonical16_bwd_pack(const float* const* w, void* packed, hipStream_t st) {
     char* out = (char*)packed;
+    int* kexp = reinterpret_cast<int*>(out + CB16_BYTES);
+    const int sizes[9] = {256 * 63, 256 * 256, 256 * 256, 256 * 256, 256 * 256, 256 * 319, 256 * 256, 256 * 256, 4 * 256};
+    int rc;
+    if ((rc = launch_layer_exp(w, sizes, 9, kexp, st))) return rc;
     auto launch = [&](const PackBwd16& d) {
         const int64_t n = (int64_t)d.NT * 2 * d.NK * 256;
         hipLaunchKernelGGL(pack_bwd16_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d, out);
         return check_launch("hnrf pack (backward, f16x3)");
     };
-    int rc;
-    if ((rc = launch(PackBwd16{w[8], 4, 256, 8, 1, PE16_NONE, 0, 1, CB16_HEAD}))) return rc;
+    if ((rc = launch(PackBwd16{w[8], 4, 256, 8, 1, PE16_NONE, 0, 1, CB16_HEAD, kexp + 8}))) return rc;
     for (int l = 7; l >= 6; --l)
-        if ((rc = launch(PackBwd16{w[l], 256, 256, 8, 16, PE16_NONE, 0, 0, CB16_L7 + (7 - l) * CB16_FULL}))) return rc;
-    if ((rc = launch(PackBwd16{w[5], 256, 319, 8, 16, PE16_NONE, 63, 0, CB16_L7 + 2 * CB16_FULL}))) return rc;
-    if ((rc = launch(PackBwd16{w[5], 256, 319, 2, 16, PE16_CANONICAL, 0, 0, CB16_L5P}))) return rc;
+        if ((rc = launch(PackBwd16{w[l], 256, 256, 8, 16, PE16_NONE, 0, 0, CB16_L7 + (7 - l) * CB16_FULL, kexp + l}))) return rc;
+    if ((rc = launch(PackBwd16{w[5], 256, 319, 8, 16, PE16_NONE, 63, 0, CB16_L7 + 2 * CB16_FULL, kexp + 5}))) return rc;
+    if ((rc = launch(PackBwd16{w[5], 256, 319, 2, 16, PE16_CANONICAL, 0, 0, CB16_L5P, kexp + 5}))) return rc;
     for (int l = 4; l >= 1; --l)
-        if ((rc = launch(PackBwd16{w[l], 256, 256, 8, 16, PE16_NONE, 0, 0, CB16_L4 + (4 - l) * CB16_FULL}))) return rc;
-    return launch(PackBwd16{w[0], 256, 63, 2, 16, PE16_CANONICAL, 0, 0, CB16_L0P});
+        if ((rc = launch(PackBwd16{w[l], 256, 256, 8, 16, PE16_NONE, 0, 0, CB16_L4 + (4 - l) * CB16_FULL, kexp + l}))) return rc;
+    return launch(PackBwd16{w[0], 256, 63, 2, 16, PE16_CANONICAL, 0, 0, CB16_L0P, kexp});
 }
 
+// half != 0: dZ is an f16 matrix in the chain's scaled domain and dz_amax receives the [8] scales instead of maxima
 int canonical16_bwd(const float* xyz, const float* d_raw, const uint32_t* relu_bits, const void* packed, int64_t P,
-                    const float* d_raw_amax, float* dZ, float* d_xyz, float* dz_amax, hipStream_t st) {
+                    const float* d_raw_amax, float* dZ, float* d_xyz, float* dz_amax, int half, hipStream_t st) {
     constexpr int lds = CNL16_BIAS_LDS + PE_STASH + RING * CNL16_SLAB;
-    static unsigned long long lds_done = 0;
-    if (int rc = reserve_lds((const void*)canonical_bwd16_kernel, lds, lds_done, "hnrf_canonical_bwd (f16x3)")) return rc;
-    hipLaunchKernelGGL(canonical_bwd16_kernel, dim3((unsigned)((P + 127) / 128)), dim3(256), lds, st, xyz,
-                       (const float4*)d_raw, relu_bits, (const char*)packed, P, d_raw_amax, dZ, d_xyz, dz_amax);
+    static unsigned long long lds_done = 0, lds_done_h = 0;
+    const dim3 grid((unsigned)((P + 127) / 128));
+    if (half) {
+        if (int rc = reserve_lds((const void*)canonical_bwd16_kernel<true>, lds, lds_done_h, "hnrf_canonical_bwd (f16x3, f16 operands)")) return rc;
+        hipLaunchKernelGGL(canonical_bwd16_kernel<true>, grid, dim3(256), lds, st, xyz, (const float4*)d_raw, relu_bits,
+                           (const char*)packed, P, d_raw_amax, dZ, d_xyz, dz_amax);
+    } else {
+        if (int rc = reserve_lds((const void*)canonical_bwd16_kernel<false>, lds, lds_done, "hnrf_canonical_bwd (f16x3)")) return rc;
+        hipLaunchKernelGGL(canonical_bwd16_kernel<false>, grid, dim3(256), lds, st, xyz, (const float4*)d_raw, relu_bits,
+                           (const char*)packed, P, d_raw_amax, dZ, d_xyz, dz_amax);
+    }
     return check_launch("hnrf_canonical_bwd (f16x3)");
 }
 
-size_t nonrigid16_bwd_bytes() { return (size_t)NB16_BYTES; }
+size_t nonrigid16_bwd_bytes() { return (size_t)NB16_BYTES + 256; }
 
 int nonrigid16_bwd_pack(const float* const* w, void* packed, hipStream_t st) {
     char* out = (char*)packed;
+    int* kexp = reinterpret_cast<int*>(out + NB16_BYTES);
+    const int sizes[7] = {128 * 105, 128 * 128, 128 * 128, 128 * 128, 128 * 164, 128 * 128, 3 * 128};
+    int rc;
+    if ((rc = launch_layer_exp(w, sizes, 7, kexp, st))) return rc;
     auto launch = [&](const PackBwd16& d) {
         const int64_t n = (int64_t)d.NT * 2 * d.NK * 256;
         hipLaunchKernelGGL(pack_bwd16_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d, out);
         return check_launch("hnrf pack (backward, f16x3)");
     };
-    int rc;
-    if ((rc = launch(PackBwd16{w[6], 3, 128, 4, 1, PE16_NONE, 0, 1, NB16_HEAD}))) return rc;
-    if ((rc = launch(PackBwd16{w[5], 128, 128, 4, 8, PE16_NONE, 0, 0, NB16_L5}))) return rc;
-    if ((rc = launch(PackBwd16{w[4], 128, 164, 4, 8, PE16_NONE, 0, 0, NB16_L5 + NB16_FULL}))) return rc;
-    if ((rc = launch(PackBwd16{w[4], 128, 164, 2, 8, PE16_NONRIGID, 128, 0, NB16_L4P}))) return rc;
+    if ((rc = launch(PackBwd16{w[6], 3, 128, 4, 1, PE16_NONE, 0, 1, NB16_HEAD, kexp + 6}))) return rc;
+    if ((rc = launch(PackBwd16{w[5], 128, 128, 4, 8, PE16_NONE, 0, 0, NB16_L5, kexp + 5}))) return rc;
+    if ((rc = launch(PackBwd16{w[4], 128, 164, 4, 8, PE16_NONE, 0, 0, NB16_L5 + NB16_FULL, kexp + 4}))) return rc;
+    if ((rc = launch(PackBwd16{w[4], 128, 164, 2, 8, PE16_NONRIGID, 128, 0, NB16_L4P, kexp + 4}))) return rc;
     for (int l = 3; l >= 1; --l)
-        if ((rc = launch(PackBwd16{w[l], 128, 128, 4, 8, PE16_NONE, 0, 0, NB16_L3 + (3 - l) * NB16_FULL}))) return rc;
-    return launch(PackBwd16{w[0], 128, 105, 2, 8, PE16_NONRIGID, 69, 0, NB16_L0P});
+        if ((rc = launch(PackBwd16{w[l], 128, 128, 4, 8, PE16_NONE, 0, 0, NB16_L3 + (3 - l) * NB16_FULL, kexp + l}))) return rc;
+    return launch(PackBwd16{w[0], 128, 105, 2, 8, PE16_NONRIGID, 69, 0, NB16_L0P, kexp});
 }
 
 int nonrigid16_bwd(const float* x_skel, const float* hann_w, const float* d_xyz, const uint32_t* relu_bits,
                    const void* packed, int64_t P, const float* d_xyz_amax, float* dZ, float* d_x_skel, float* dz_amax,
-                   hipStream_t st) {
+                   int half, hipStream_t st) {
     constexpr int lds = NR16_BIAS_LDS + PE_STASH + RING * NR16_SLAB;
-    static unsigned long long lds_done = 0;
-    if (int rc = reserve_lds((const void*)nonrigid_bwd16_kernel, lds, lds_done, "hnrf_nonrigid_bwd (f16x3)")) return rc;
-    hipLaunchKernelGGL(nonrigid_bwd16_kernel, dim3((unsigned)((P + 127) / 128)), dim3(256), lds, st, x_skel, hann_w, d_xyz,
-                       relu_bits, (const char*)packed, P, d_xyz_amax, dZ, d_x_skel, dz_amax);
+    static unsigned long long lds_done = 0, lds_done_h = 0;
+    const dim3 grid((unsigned)((P + 127) / 128));
+    if (half) {
+        if (int rc = reserve_lds((const void*)nonrigid_bwd16_kernel<true>, lds, lds_done_h, "hnrf_nonrigid_bwd (f16x3, f16 operands)")) return rc;
+        hipLaunchKernelGGL(nonrigid_bwd16_kernel<true>, grid, dim3(256), lds, st, x_skel, hann_w, d_xyz, relu_bits,
+                           (const char*)packed, P, d_xyz_amax, dZ, d_x_skel, dz_amax);
+    } else {
+        if (int rc = reserve_lds((const void*)nonrigid_bwd16_kernel<false>, lds, lds_done, "hnrf_nonrigid_bwd (f16x3)")) return rc;
+        hipLaunchKernelGGL(nonrigid_bwd16_kernel<false>, grid, dim3(256), lds, st, x_skel, hann_w, d_xyz, relu_bits,
+                           (const char*)packed, P, d_xyz_amax, dZ, d_x_skel, dz_amax);
+    }
     return check_launch("hnrf_nonrigid_bwd (f16x3)");
 }
 

@@ -11,6 +11,8 @@ import torch
 from . import _lib
 
 MLP_MODES = {'f32': 0, 'f16x3': 1}
+# training entry points only: split-f16 arithmetic with the saved weight-gradient operands (activations, dZ) in f16
+TRAIN_MODES = {'f32': 0, 'f16x3': 1, 'f16x3h': 2}
 
 
 def _ptr(t):
@@ -233,31 +235,36 @@ def render_rays_term(rays_o, rays_d, near, far, t_rand, motion_Rs, motion_Ts, vo
 # ----------------------------------------------------------------------------- training
 def canonical_train(xyz, packed, mode='f32'):
     """hnrf_canonical_fwd_train: raw (...,4), pe (P,63), acts (8,P,256), relu sign masks (8,P,8) int32.
-    ``packed`` must have been made for the same ``mode``."""
+    ``packed`` must have been made for the same arithmetic (the 'f16x3' image serves 'f16x3h').  mode 'f16x3h':
+    acts is float16 in the BLOCKED layout of hnrf_mlp_dw_h, (8, P rounded up to 128, 256) -- opaque, for mlp_dw_h(...,
+    x_blocked=True) -- and pe a row-major float16 (P,64) matrix whose last column is zero."""
     lib = _lib.load()
     _chk(xyz, packed)
     P = xyz.numel() // 3
     dev = xyz.device
+    half = mode == 'f16x3h'
     raw = torch.empty(*xyz.shape[:-1], 4, device=dev)
-    pe = torch.empty(P, 63, device=dev)
-    acts = torch.empty(8, P, 256, device=dev)
+    pe = torch.empty(P, 64, device=dev, dtype=torch.float16) if half else torch.empty(P, 63, device=dev)
+    acts = torch.empty(8, (P + 127) // 128 * 128, 256, device=dev, dtype=torch.float16) if half else torch.empty(8, P, 256, device=dev)
     bits = torch.empty(8, P, 8, dtype=torch.int32, device=dev)
-    _lib.check(lib.hnrf_canonical_fwd_train(_ptr(xyz), _ptr(packed), MLP_MODES[mode], P, _ptr(raw), _ptr(pe),
+    _lib.check(lib.hnrf_canonical_fwd_train(_ptr(xyz), _ptr(packed), TRAIN_MODES[mode], P, _ptr(raw), _ptr(pe),
                                             _ptr(acts), bits.data_ptr(), _stream()), 'hnrf_canonical_fwd_train')
     return raw, pe, acts, bits
 
 
 def nonrigid_train(x_skel, hann_w, packed, mode='f32'):
-    """hnrf_nonrigid_fwd_train: xyz, offsets, pe (P,36), acts (6,P,128), relu sign masks (6,P,4) int32."""
+    """hnrf_nonrigid_fwd_train: xyz, offsets, pe (P,36), acts (6,P,128), relu sign masks (6,P,4) int32; mode 'f16x3h':
+    float16 acts and a float16 pe (P,64) with columns 36.. zero."""
     lib = _lib.load()
     _chk(x_skel, hann_w, packed)
     P = x_skel.numel() // 3
     dev = x_skel.device
+    half = mode == 'f16x3h'
     xyz, offsets = torch.empty_like(x_skel), torch.empty_like(x_skel)
-    pe = torch.empty(P, 36, device=dev)
-    acts = torch.empty(6, P, 128, device=dev)
+    pe = torch.empty(P, 64, device=dev, dtype=torch.float16) if half else torch.empty(P, 36, device=dev)
+    acts = torch.empty(6, (P + 127) // 128 * 128, 128, device=dev, dtype=torch.float16) if half else torch.empty(6, P, 128, device=dev)
     bits = torch.empty(6, P, 4, dtype=torch.int32, device=dev)
-    _lib.check(lib.hnrf_nonrigid_fwd_train(_ptr(x_skel), _ptr(hann_w), _ptr(packed), MLP_MODES[mode], P, _ptr(xyz),
+    _lib.check(lib.hnrf_nonrigid_fwd_train(_ptr(x_skel), _ptr(hann_w), _ptr(packed), TRAIN_MODES[mode], P, _ptr(xyz),
                                            _ptr(offsets), _ptr(pe), _ptr(acts), bits.data_ptr(), _stream()),
                'hnrf_nonrigid_fwd_train')
     return xyz, offsets, pe, acts, bits
@@ -290,40 +297,45 @@ def pe_bwd(x, g, hann_w, n_bands, include_input, out=None):
 
 def canonical_bwd(xyz, d_raw, bits, weights, mode='f32'):
     """dX chain of the canonical MLP: returns dZ (8,P,256), d_xyz (P,3) and amax (8,64) (max over row l bounds
-    |dZ_l|).  bits: sign masks from canonical_train."""
+    |dZ_l|).  bits: sign masks from canonical_train.  mode 'f16x3h': dZ is float16 in the chain's scaled domain and the
+    third result is scale (8,): the power of two dZ_l was multiplied by (mlp_dw_h divides it out)."""
     lib = _lib.load()
     _chk(xyz, d_raw, *weights)
     P = xyz.numel() // 3
     assert bits.shape == (8, P, 8) and bits.dtype == torch.int32 and bits.is_contiguous()
     assert d_raw.numel() == 4 * P and len(weights) == 9
-    m = MLP_MODES[mode]
-    packed = torch.empty(lib.hnrf_canonical_bwd_packed_bytes(m) // 4, device=xyz.device)
+    half = mode == 'f16x3h'
+    m = MLP_MODES['f16x3' if half else mode]
+    packed = torch.empty((lib.hnrf_canonical_bwd_packed_bytes(m) + 3) // 4, device=xyz.device)
     _lib.check(lib.hnrf_canonical_bwd_pack(_ptr_array(weights), m, _ptr(packed), _stream()), 'hnrf_canonical_bwd_pack')
-    d_raw_amax = d_raw.abs().amax().reshape(1) if mode == 'f16x3' else None
-    dZ = torch.empty(8, P, 256, device=xyz.device)
+    d_raw_amax = d_raw.abs().amax().reshape(1) if mode != 'f32' else None
+    dZ = torch.empty(8, (P + 127) // 128 * 128, 256, device=xyz.device, dtype=torch.float16) if half else torch.empty(8, P, 256, device=xyz.device)
     d_xyz = torch.empty(P, 3, device=xyz.device)
-    amax = torch.empty(8, 64, device=xyz.device)
-    _lib.check(lib.hnrf_canonical_bwd(_ptr(xyz), _ptr(d_raw), bits.data_ptr(), _ptr(packed), m, _ptr(d_raw_amax), P,
-                                      _ptr(dZ), _ptr(d_xyz), _ptr(amax), _stream()), 'hnrf_canonical_bwd')
+    amax = torch.empty(8, device=xyz.device) if half else torch.empty(8, 64, device=xyz.device)
+    _lib.check(lib.hnrf_canonical_bwd(_ptr(xyz), _ptr(d_raw), bits.data_ptr(), _ptr(packed), TRAIN_MODES[mode],
+                                      _ptr(d_raw_amax), P, _ptr(dZ), _ptr(d_xyz), _ptr(amax), _stream()), 'hnrf_canonical_bwd')
     return dZ, d_xyz, amax
 
 
 def nonrigid_bwd(x_skel, hann_w, d_xyz, bits, weights, mode='f32'):
-    """dX chain of the non-rigid MLP: returns dZ (6,P,128), d_x_skel (P,3) (identity path included), amax (6,64)."""
+    """dX chain of the non-rigid MLP: returns dZ (6,P,128), d_x_skel (P,3) (identity path included), amax (6,64)
+    (mode 'f16x3h': float16 dZ and scale (6,), see canonical_bwd)."""
     lib = _lib.load()
     _chk(x_skel, hann_w, d_xyz, *weights)
     P = x_skel.numel() // 3
     assert bits.shape == (6, P, 4) and bits.dtype == torch.int32 and bits.is_contiguous()
     assert d_xyz.numel() == 3 * P and len(weights) == 7
-    m = MLP_MODES[mode]
-    packed = torch.empty(lib.hnrf_nonrigid_bwd_packed_bytes(m) // 4, device=x_skel.device)
+    half = mode == 'f16x3h'
+    m = MLP_MODES['f16x3' if half else mode]
+    packed = torch.empty((lib.hnrf_nonrigid_bwd_packed_bytes(m) + 3) // 4, device=x_skel.device)
     _lib.check(lib.hnrf_nonrigid_bwd_pack(_ptr_array(weights), m, _ptr(packed), _stream()), 'hnrf_nonrigid_bwd_pack')
-    d_amax = d_xyz.abs().amax().reshape(1) if mode == 'f16x3' else None
-    dZ = torch.empty(6, P, 128, device=x_skel.device)
+    d_amax = d_xyz.abs().amax().reshape(1) if mode != 'f32' else None
+    dZ = torch.empty(6, (P + 127) // 128 * 128, 128, device=x_skel.device, dtype=torch.float16) if half else torch.empty(6, P, 128, device=x_skel.device)
     d_x_skel = torch.empty(P, 3, device=x_skel.device)
-    amax = torch.empty(6, 64, device=x_skel.device)
-    _lib.check(lib.hnrf_nonrigid_bwd(_ptr(x_skel), _ptr(hann_w), _ptr(d_xyz), bits.data_ptr(), _ptr(packed), m,
-                                     _ptr(d_amax), P, _ptr(dZ), _ptr(d_x_skel), _ptr(amax), _stream()), 'hnrf_nonrigid_bwd')
+    amax = torch.empty(6, device=x_skel.device) if half else torch.empty(6, 64, device=x_skel.device)
+    _lib.check(lib.hnrf_nonrigid_bwd(_ptr(x_skel), _ptr(hann_w), _ptr(d_xyz), bits.data_ptr(), _ptr(packed),
+                                     TRAIN_MODES[mode], _ptr(d_amax), P, _ptr(dZ), _ptr(d_x_skel), _ptr(amax), _stream()),
+               'hnrf_nonrigid_bwd')
     return dZ, d_x_skel, amax
 
 
@@ -360,15 +372,20 @@ def mlp_dw(dZ, X, dW_out=None, want_db=True, mode='f32', dz_amax=None):
     return dW_out, db
 
 
-def mlp_dw_h(dZ, X, dW_out=None, want_db=True, dz_scale=None, n_in=None):
+def mlp_dw_h(dZ, X, dW_out=None, want_db=True, dz_scale=None, n_in=None, P=None, z_blocked=False, x_blocked=False):
     """hnrf_mlp_dw_h: dW = dZ^T X / scale (and db) from f16 operands.  dZ [P, n_out] f16 (n_out 128 | 256) or, for a
     head, fp32 [P, n_out <= 4]; X [P, >= n_in] f16 whose rows are zero-padded to 64 / 128 / 256 columns; ``n_in``:
-    columns of dW (default X.shape[1]); dz_scale: device scalar the stored dZ was multiplied by."""
+    columns of dW (default X.shape[1]); dz_scale: device scalar the stored dZ was multiplied by.  ``z_blocked`` /
+    ``x_blocked``: the matrix is one layer of the blocked buffers canonical_train / canonical_bwd return in mode
+    'f16x3h' (shape [P padded to 128, width]); ``P`` then gives the true sample count."""
     lib = _lib.load()
     head = dZ.shape[1] <= 4
     assert X.dtype == torch.float16 and dZ.dtype == (torch.float32 if head else torch.float16) and dZ.is_cuda and X.is_cuda
-    assert dZ.dim() == 2 and X.dim() == 2 and dZ.stride(1) == 1 and X.stride(1) == 1 and dZ.shape[0] == X.shape[0]
-    P, n_out = dZ.shape
+    assert dZ.dim() == 2 and X.dim() == 2 and dZ.stride(1) == 1 and X.stride(1) == 1
+    n_out = dZ.shape[1]
+    P = int(dZ.shape[0] if P is None else P)
+    assert dZ.shape[0] >= P and X.shape[0] >= P and (z_blocked or x_blocked or dZ.shape[0] == X.shape[0])
+    assert (not z_blocked or dZ.is_contiguous()) and (not x_blocked or X.is_contiguous())
     n_in = int(X.shape[1] if n_in is None else n_in)
     if dW_out is None:
         dW_out = torch.empty(n_out, n_in, device=dZ.device)
@@ -381,9 +398,10 @@ def mlp_dw_h(dZ, X, dW_out=None, want_db=True, dz_scale=None, n_in=None):
     ws = _dw_ws.get(key)
     if ws is None or ws.numel() < need:
         ws = _dw_ws[key] = torch.empty(need, dtype=torch.uint8, device=dZ.device)
-    _lib.check(lib.hnrf_mlp_dw_h(dZ.data_ptr(), dZ.stride(0), X.data_ptr(), X.stride(0), P, n_out, n_in, _ptr(dz_scale),
-                                 dW_out.data_ptr(), dW_out.stride(0), _ptr(db), ws.data_ptr(), ws.numel(), _stream()),
-               'hnrf_mlp_dw_h')
+    layout = (1 if z_blocked else 0) | (2 if x_blocked else 0)
+    _lib.check(lib.hnrf_mlp_dw_h(dZ.data_ptr(), dZ.stride(0), X.data_ptr(), X.stride(0), P, n_out, n_in, layout,
+                                 _ptr(dz_scale), dW_out.data_ptr(), dW_out.stride(0), _ptr(db), ws.data_ptr(), ws.numel(),
+                                 _stream()), 'hnrf_mlp_dw_h')
     return dW_out, db
 
 

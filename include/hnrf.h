@@ -37,6 +37,12 @@ extern "C" {
 /* arithmetic of the per-sample MLP GEMMs */
 #define HNRF_MLP_F32    0      /* v_mfma_f32_32x32x2_f32: exact fp32 fma chain   */
 #define HNRF_MLP_F16X3  1      /* split-fp16 (hi+lo) inputs, 3 MFMAs, fp32 accum */
+#define HNRF_MLP_F16X3_H 2     /* training entry points only (hnrf_*_fwd_train, hnrf_*_bwd): HNRF_MLP_F16X3 arithmetic with
+                                * the saved weight-gradient operands in f16 -- acts / dZ are f16 matrices of the same
+                                * layer count in the BLOCKED layout of hnrf_mlp_dw_h (every layer padded to a multiple of 128
+                                * samples: [L][ceil(P / 128) * 128][width]), pe_out is row-major f16 [P][64] (zero-padded), dZ
+                                * carries the chain's power-of-two scale and dz_amax receives that scale per layer ([L]
+                                * floats) for hnrf_mlp_dw_h.  Packed images are the HNRF_MLP_F16X3 ones. */
 
 int         hnrf_abi_version(void);
 const char* hnrf_last_error(void);
@@ -227,9 +233,14 @@ int hnrf_mlp_dw(const float* dZ, int64_t ldz, const float* X, int64_t ldx, int64
  * fp32 accumulation over the samples; both operands reach the matrix pipe through gfx950's transposed LDS read
  * (ds_read_b64_tr_b16).  Each operand is rounded to 11 bits, unbiased: the relative error of a sum over N samples is
  * ~2^-12 / sqrt(N).  n_out <= 4 (heads): dZ is the fp32 [P, n_out] gradient at the head output, X the f16 activations.
- * Same shapes, workspace rules and determinism as hnrf_mlp_dw. */
+ * Same shapes, workspace rules and determinism as hnrf_mlp_dw.
+ * layout: 0 = both matrices row-major; HNRF_DWH_DZ_BLOCKED / HNRF_DWH_X_BLOCKED = the matrix is in the BLOCKED layout
+ * the HNRF_MLP_F16X3_H training kernels write (32-sample blocks of [32-feature tile][4 groups][2][32 samples][4 halves],
+ * layers padded to a multiple of 128 samples; row strides are ignored for it).  Built: none, dZ only, both. */
+#define HNRF_DWH_DZ_BLOCKED 1
+#define HNRF_DWH_X_BLOCKED  2
 size_t hnrf_mlp_dw_h_workspace_bytes(int64_t P, int n_out, int n_in);
-int hnrf_mlp_dw_h(const void* dZ, int64_t ldz, const void* X, int64_t ldx, int64_t P, int n_out, int n_in,
+int hnrf_mlp_dw_h(const void* dZ, int64_t ldz, const void* X, int64_t ldx, int64_t P, int n_out, int n_in, int layout,
                   const float* dz_scale, float* dW, int64_t ldw, float* db, void* workspace, size_t workspace_bytes,
                   void* stream);
 
