@@ -63,6 +63,64 @@ def _weight_grads_h(dZ, scale, acts, pe, dY, weights, skip_layer, skip_order, np
     return gW, gb
 
 
+ACT_MIN, ACT_MAX = 2.0 ** -8, 60000.0
+
+
+class OperandRangeGuard:
+    """Run-time check of the premise of the f16 / split-f16 training arithmetic: every layer's largest
+    activation must sit inside f16's useful range -- below ~2^-8 the operands of the weight-gradient products lose
+    their bits to f16 subnormals, at 65504 the kernels clamp -- and the incoming gradient must be finite.  Checked every
+    ``cfg.amd.train_check_every`` backward passes (one reduction over the saved activations, ~0.5 ms); the verdict is
+    read back without a synchronisation and raised at the next check.  Remedy when it fires: cfg.amd.train_mlp_mode =
+    train_chain_mode = train_dw_mode = 'f32' (exact fp32 MFMA kernels)."""
+
+    def __init__(self):
+        self.calls = 0
+        self.pending = []
+
+    @staticmethod
+    def flags(acts_list, d_in):
+        """device bool tensor [too_small, too_large, non_finite_gradient]"""
+        amax = torch.cat([a.abs().amax(dim=(1, 2)).float() for a in acts_list if a is not None])
+        fin = torch.isfinite(d_in).all()
+        return torch.stack([(amax < ACT_MIN).any(), (amax >= ACT_MAX).any(), ~fin])
+
+    def maybe_check(self, acts_list, d_in):
+        every = int(amd_option('train_check_every', 200))
+        self.calls += 1
+        self.poll()
+        if every <= 0 or (self.calls - 1) % every:
+            return
+        fl = self.flags(acts_list, d_in)
+        host = torch.empty(3, dtype=torch.bool, pin_memory=True)
+        host.copy_(fl, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        self.pending.append((host, ev, self.calls))
+
+    def poll(self, wait=False):
+        keep = []
+        for host, ev, call in self.pending:
+            if wait:
+                ev.synchronize()
+            if not ev.query():
+                keep.append((host, ev, call))
+                continue
+            small, large, nonfinite = (bool(x) for x in host)
+            if small or large or nonfinite:
+                self.pending = []
+                raise ops._lib.HnrfError(
+                    'training operands left the range of the split-f16 arithmetic at backward pass %d: %s.  Set '
+                    "cfg.amd.train_mlp_mode = train_chain_mode = train_dw_mode = 'f32' for this model." % (
+                        call, ', '.join(n for n, f in (('a layer with all activations below 2^-8', small),
+                                                       ('activations at the f16 limit (clamped)', large),
+                                                       ('non-finite incoming gradient', nonfinite)) if f)))
+        self.pending = keep
+
+
+range_guard = OperandRangeGuard()
+
+
 def training_modes():
     """(forward, chain, dW) arithmetic of the training kernels and whether the saved operands are f16.
     cfg.amd.train_operands = 'f16' needs split-f16 arithmetic in the forward and the chain."""
@@ -124,6 +182,8 @@ class RenderRays(torch.autograd.Function):
         # canonical MLP (skip layer 5 takes [PE63 | h]): dX chain with the PE backward fused, then the weight gradients
         d_raw = d_raw.view(P, 4)
         _, chain_mode, dw_mode, _ = training_modes()
+        if chain_mode != 'f32' or dw_mode != 'f32':
+            range_guard.maybe_check([acts_c, acts_n], d_raw)
         if ctx.half:
             dZc, d_xyz, sc_c = ops.canonical_bwd(xyz.reshape(P, 3), d_raw, bits_c, cn_w, 'f16x3h')
             gWc, gbc = _weight_grads_h(dZc, sc_c, acts_c, pe_c, d_raw, cn_w, skip_layer=5, skip_order='pe_first', npe=63)

@@ -129,6 +129,9 @@ _DEFAULTS = {
         # buffers; every product of the weight-gradient sums uses 11-bit operands, fp32 accumulation over >= 10^5
         # samples), 'f32' = fp32 storage, 22-bit split operands in the weight-gradient kernel
         'train_operands': 'f16',
+        # every this many backward passes the saved activations and the incoming gradient are checked against the
+        # range the split-f16 / f16 arithmetic assumes (autograd.OperandRangeGuard); 0 = never
+        'train_check_every': 200,
         # materialise the per-sample diagnostic outputs the reference always
         # returns (backward_motion_weights, xyz_on_rays, ...; ~17 KB/ray).
         'diagnostics': True,

@@ -647,6 +647,82 @@ __global__ __launch_bounds__(NI) void mlp_dwh_head_kernel(const float* __restric
     if (dbpart != nullptr && i < 4) dbpart[(int64_t)blockIdx.x * 4 + i] = b;
 }
 
+// Head layers, blocked f16 activations, coalesced: the 256 threads of a block take the 256 8-byte granules of one
+// 32-feature tile of a 32-sample block (thread = (feature group k, sample slot): 2 KiB contiguous per step), every
+// thread keeps 4 features x 4 outputs per tile for ITS sample slot, and the 32 slots of a group are summed by wave
+// shuffles once at the end.  Partials in the layout of mlp_dw_head_kernel.
+template <int NI>
+__global__ __launch_bounds__(256) void mlp_dwh_head_blk_kernel(const float* __restrict__ dY, int64_t ldy, int n_out,
+                                                               const _Float16* __restrict__ X, int64_t P, int64_t per_wg,
+                                                               float* __restrict__ part, float* __restrict__ dbpart) {
+    constexpr int NTILE = NI / 32;
+    const int tid = threadIdx.x, k = tid >> 5, slot = tid & 31, c = slot ^ (4 * k);
+    const int64_t s0 = (int64_t)blockIdx.x * per_wg;                 // multiple of 32
+    const int64_t s1 = s0 + per_wg < P ? s0 + per_wg : P;
+    float acc[NTILE][4][4];
+#pragma unroll
+    for (int t = 0; t < NTILE; ++t)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int o = 0; o < 4; ++o) acc[t][j][o] = 0.f;
+    float bsum[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int64_t sb = s0; sb < s1; sb += 32) {
+        const int64_t s = sb + c;
+        float g[4] = {0.f, 0.f, 0.f, 0.f};
+        if (s < s1) {
+#pragma unroll
+            for (int o = 0; o < 4; ++o) g[o] = o < n_out ? dY[s * ldy + o] : 0.f;
+        }
+#pragma unroll
+        for (int o = 0; o < 4; ++o) bsum[o] += g[o];
+        const _Float16* xb = X + (sb >> 5) * (int64_t)(NI * 32) + tid * 4;
+        h16x4 xv[NTILE];
+#pragma unroll
+        for (int t = 0; t < NTILE; ++t) xv[t] = *reinterpret_cast<const h16x4*>(xb + t * 1024);
+#pragma unroll
+        for (int t = 0; t < NTILE; ++t)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float x = (float)xv[t][j];
+#pragma unroll
+                for (int o = 0; o < 4; ++o) acc[t][j][o] = fmaf(g[o], x, acc[t][j][o]);
+            }
+    }
+    // sum over the 32 sample slots of each feature group (a half wave)
+#pragma unroll
+    for (int t = 0; t < NTILE; ++t)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int o = 0; o < 4; ++o) {
+                float v = acc[t][j][o];
+#pragma unroll
+                for (int off = 16; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+                acc[t][j][o] = v;
+            }
+    float* out = part + (int64_t)blockIdx.x * 4 * NI;
+    if (slot == 0) {
+#pragma unroll
+        for (int t = 0; t < NTILE; ++t)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int f = 32 * t + 8 * (k >> 1) + 4 * (k & 1) + j;
+#pragma unroll
+                for (int o = 0; o < 4; ++o) out[o * NI + f] = acc[t][j][o];
+            }
+    }
+    if (dbpart != nullptr && k == 0) {                               // feature group 0 saw every sample once
+#pragma unroll
+        for (int o = 0; o < 4; ++o) {
+            float v = bsum[o];
+#pragma unroll
+            for (int off = 16; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+            if (slot == 0) dbpart[(int64_t)blockIdx.x * 4 + o] = v;
+        }
+    }
+}
+
 static bool dwh_plan(int64_t P, int n_out, int n_in, DwPlan& pl) {
     if (n_out == 256 || n_out == 128) pl.now = n_out; else if (n_out >= 1 && n_out <= 4) pl.now = 4; else return false;
     if (n_in == 256 || n_in == 128) pl.nip = n_in;
@@ -1042,8 +1118,15 @@ extern "C" int hnrf_mlp_dw_h(const void* dZ, int64_t ldz, const void* X, int64_t
 #define HNRF_DWHH(NI, XB)                                                                                              \
     hipLaunchKernelGGL((mlp_dwh_head_kernel<NI, XB>), dim3(pl.nsplit), dim3(NI), 0, st, (const float*)dZ, ldz, n_out, \
                        (const _Float16*)X, ldx, P, pl.per_wg, part, db ? dbpart : nullptr)
-        if (n_in == 256) { if (xb) HNRF_DWHH(256, true); else HNRF_DWHH(256, false); }
-        else { if (xb) HNRF_DWHH(128, true); else HNRF_DWHH(128, false); }
+        if (xb) {
+            if (n_in == 256)
+                hipLaunchKernelGGL(mlp_dwh_head_blk_kernel<256>, dim3(pl.nsplit), dim3(256), 0, st, (const float*)dZ, ldz, n_out,
+                                   (const _Float16*)X, P, pl.per_wg, part, db ? dbpart : nullptr);
+            else
+                hipLaunchKernelGGL(mlp_dwh_head_blk_kernel<128>, dim3(pl.nsplit), dim3(256), 0, st, (const float*)dZ, ldz, n_out,
+                                   (const _Float16*)X, P, pl.per_wg, part, db ? dbpart : nullptr);
+        } else if (n_in == 256) HNRF_DWHH(256, false);
+        else HNRF_DWHH(128, false);
 #undef HNRF_DWHH
     } else {
         HNRF_REQUIRE((zb || ldz >= pl.now) && (xb || ldx >= pl.nip) && ldw >= n_in, HNRF_E_ARG,

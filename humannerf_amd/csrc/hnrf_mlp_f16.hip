@@ -1137,26 +1137,29 @@ struct PackBwd16 {
     int col0;
     int head;              // 1: K = the n_out (<= 4) head outputs, elements 0..3 of lane half 0 of k-step 0
     int64_t off;           // byte offset of the stage's first slab
-    const int* kexp;       // device: this layer's layer_exponent (weights are stored x 2^k)
+    const float* amax;     // device: max |W| of this layer; the image is stored x 2^layer_exponent(amax)
 };
 
-// exponent table of a whole MLP: block l reduces max |W_l| and writes layer_exponent of it
+// max |W_l| of every layer of an MLP: grid (layers, 16 slices), float maxima combined with an integer atomicMax (non-negative
+// floats order like their bit patterns); the table is zeroed before the launch.  layer_exponent() of an entry is the
+// power of two that layer's image is stored with.
 struct LayerSet {
     const float* w[9];
     int n[9];
 };
-__global__ __launch_bounds__(256) void layer_exp_kernel(LayerSet ls, int* __restrict__ out) {
+__global__ __launch_bounds__(256) void layer_amax_kernel(LayerSet ls, float* __restrict__ out) {
     __shared__ float red[256];
     const float* W = ls.w[blockIdx.x];
+    const int n = ls.n[blockIdx.x];
     float m = 0.f;
-    for (int e = threadIdx.x; e < ls.n[blockIdx.x]; e += 256) m = fmaxf(m, fabsf(W[e]));
+    for (int e = blockIdx.y * 256 + threadIdx.x; e < n; e += 256 * gridDim.y) m = fmaxf(m, fabsf(W[e]));
     red[threadIdx.x] = m;
     __syncthreads();
     for (int st = 128; st >= 1; st >>= 1) {
         if ((int)threadIdx.x < st) red[threadIdx.x] = fmaxf(red[threadIdx.x], red[threadIdx.x + st]);
         __syncthreads();
     }
-    if (threadIdx.x == 0) out[blockIdx.x] = layer_exponent(red[0]);
+    if (threadIdx.x == 0) atomicMax(reinterpret_cast<unsigned int*>(out) + blockIdx.x, __float_as_uint(red[0]));
 }
 
 __global__ void pack_bwd16_kernel(PackBwd16 d, char* __restrict__ packed) {
@@ -1172,7 +1175,7 @@ __global__ void pack_bwd16_kernel(PackBwd16 d, char* __restrict__ packed) {
     const int j0 = (u & 3) * 2;
     const int h = lane >> 5;
     const int rho = 32 * t + (lane & 31);
-    const int kexp = *d.kexp;
+    const int kexp = layer_exponent(*d.amax);
     int col;
     if (d.row_kind == PE16_NONE) {
         col = d.col0 + rho;
@@ -1204,7 +1207,7 @@ constexpr int64_t CB16_L7 = CB16_HEAD + 16 * KB;
 constexpr int64_t CB16_L5P = CB16_L7 + 3 * CB16_FULL;
 constexpr int64_t CB16_L4 = CB16_L5P + CB16_PE;
 constexpr int64_t CB16_L0P = CB16_L4 + 4 * CB16_FULL;
-constexpr int64_t CB16_BYTES = CB16_L0P + CB16_PE;            // followed by int kexp[9] (layer_exp_kernel), 256 bytes
+constexpr int64_t CB16_BYTES = CB16_L0P + CB16_PE;            // followed by float amax[9] (layer_amax_kernel), 256 bytes
 
 __device__ __forceinline__ void chain_amax(SaveCtx& sc, float* __restrict__ slot) {
     float m = sc.amax;
@@ -1235,7 +1238,8 @@ __global__ __launch_bounds__(256) void canonical_bwd16_kernel(const float* __res
     const int64_t slot = ((int64_t)blockIdx.x * 4 + p.wave) * 32 + (lane & 31);
     const int64_t sample = slot < P ? slot : P - 1;            // lanes past P repeat sample P-1 (same values stored)
     const int64_t stride = P * 256, bstride = P * 8;
-    const int* kt = reinterpret_cast<const int*>(packed + CB16_BYTES);      // weights of layer l are stored x 2^kt[l]
+    const float* wmax = reinterpret_cast<const float*>(packed + CB16_BYTES);
+    auto kt = [&](int l) { return layer_exponent(wmax[l]); };          // weights of layer l are stored x 2^kt(l)
 
     // non-finite incoming gradient (an overflowed loss): the scale would be undefined -- gradients of zero scale come
     // out as NaN everywhere instead of silently wrong (and the caller's finite check sees them)
@@ -1252,7 +1256,7 @@ __global__ __launch_bounds__(256) void canonical_bwd16_kernel(const float* __res
         stash_pe(p, 0, v);
     }
     SaveCtx sc;
-    float S = scale * ldexpf(1.0f, kt[8]);                      // scale of the stage being computed (dZ7 = W8^T d_raw)
+    float S = scale * ldexpf(1.0f, kt(8));                      // scale of the stage being computed (dZ7 = W8^T d_raw)
     sc.descale = 1.0f / S;
     sc.amax = 0.f;
     sc.row = dZ + 7 * stride + sample * 256 + 4 * h;
@@ -1269,7 +1273,7 @@ __global__ __launch_bounds__(256) void canonical_bwd16_kernel(const float* __res
         sc.rowh -= strideh;
         mrow -= bstride;
         if (am) am -= HNRF_AMAX_SLOTS;
-        S *= ldexpf(1.0f, kt[w_next]);
+        S *= ldexpf(1.0f, kt(w_next));
         sc.descale = 1.0f / S;
         if (sout && w_next > 0) { --sout; *sout = S; }           // (w_next = 0: the scale of layer 0's d PE, not a dZ)
     };
@@ -1345,7 +1349,7 @@ constexpr int64_t NB16_L5 = NB16_HEAD + 8 * KB;
 constexpr int64_t NB16_L4P = NB16_L5 + 2 * NB16_FULL;
 constexpr int64_t NB16_L3 = NB16_L4P + NB16_PE;
 constexpr int64_t NB16_L0P = NB16_L3 + 3 * NB16_FULL;
-constexpr int64_t NB16_BYTES = NB16_L0P + NB16_PE;            // followed by int kexp[7], 256 bytes
+constexpr int64_t NB16_BYTES = NB16_L0P + NB16_PE;            // followed by float amax[7], 256 bytes
 
 // Non-rigid MLP, split-f16 (xyz = x_skel + offset): d_x_skel = d_xyz + J_offset^T d_xyz, dZ [6][P][128].
 // HALF: see canonical_bwd16_kernel.
@@ -1367,7 +1371,8 @@ __global__ __launch_bounds__(256) void nonrigid_bwd16_kernel(const float* __rest
     const int64_t slot = ((int64_t)blockIdx.x * 4 + p.wave) * 32 + (lane & 31);
     const int64_t sample = slot < P ? slot : P - 1;
     const int64_t stride = P * 128, bstride = P * 4;
-    const int* kt = reinterpret_cast<const int*>(packed + NB16_BYTES);
+    const float* wmax = reinterpret_cast<const float*>(packed + NB16_BYTES);
+    auto kt = [&](int l) { return layer_exponent(wmax[l]); };
 
     int ex = 0;
     const float am_in = *d_xyz_amax;
@@ -1380,7 +1385,7 @@ __global__ __launch_bounds__(256) void nonrigid_bwd16_kernel(const float* __rest
         stash_pe(p, 0, v);
     }
     SaveCtx sc;
-    float S = scale * ldexpf(1.0f, kt[6]);                       // dZ5 = W6^T d_xyz
+    float S = scale * ldexpf(1.0f, kt(6));                       // dZ5 = W6^T d_xyz
     sc.descale = 1.0f / S;
     sc.amax = 0.f;
     sc.mask[2] = sc.mask[3] = 0u;
@@ -1398,7 +1403,7 @@ __global__ __launch_bounds__(256) void nonrigid_bwd16_kernel(const float* __rest
         sc.rowh -= strideh;
         mrow -= bstride;
         if (am) am -= HNRF_AMAX_SLOTS;
-        S *= ldexpf(1.0f, kt[w_next]);
+        S *= ldexpf(1.0f, kt(w_next));
         sc.descale = 1.0f / S;
         if (sout && w_next > 0) { --sout; *sout = S; }
     };
@@ -1578,19 +1583,23 @@ int nonrigid16_fwd_train(const float* x_skel, const float* hann_w, const void* p
 
 size_t canonical16_bwd_bytes() { return (size_t)CB16_BYTES + 256; }
 
-static int launch_layer_exp(const float* const* w, const int* n, int count, int* out, hipStream_t st) {
+static int launch_layer_amax(const float* const* w, const int* n, int count, float* out, hipStream_t st) {
     LayerSet ls;
     for (int i = 0; i < 9; ++i) { ls.w[i] = i < count ? w[i] : nullptr; ls.n[i] = i < count ? n[i] : 0; }
-    hipLaunchKernelGGL(layer_exp_kernel, dim3(count), dim3(256), 0, st, ls, out);
-    return check_launch("hnrf pack (layer exponents)");
+    if (hipMemsetAsync(out, 0, 64, st) != hipSuccess) {
+        set_error("hnrf pack (layer maxima): memset failed");
+        return HNRF_E_LAUNCH;
+    }
+    hipLaunchKernelGGL(layer_amax_kernel, dim3(count, 16), dim3(256), 0, st, ls, out);
+    return check_launch("hnrf pack (layer maxima)");
 }
 
 int canonical16_bwd_pack(const float* const* w, void* packed, hipStream_t st) {
     char* out = (char*)packed;
-    int* kexp = reinterpret_cast<int*>(out + CB16_BYTES);
+    float* kexp = reinterpret_cast<float*>(out + CB16_BYTES);
     const int sizes[9] = {256 * 63, 256 * 256, 256 * 256, 256 * 256, 256 * 256, 256 * 319, 256 * 256, 256 * 256, 4 * 256};
     int rc;
-    if ((rc = launch_layer_exp(w, sizes, 9, kexp, st))) return rc;
+    if ((rc = launch_layer_amax(w, sizes, 9, kexp, st))) return rc;
     auto launch = [&](const PackBwd16& d) {
         const int64_t n = (int64_t)d.NT * 2 * d.NK * 256;
         hipLaunchKernelGGL(pack_bwd16_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d, out);
@@ -1628,10 +1637,10 @@ size_t nonrigid16_bwd_bytes() { return (size_t)NB16_BYTES + 256; }
 
 int nonrigid16_bwd_pack(const float* const* w, void* packed, hipStream_t st) {
     char* out = (char*)packed;
-    int* kexp = reinterpret_cast<int*>(out + NB16_BYTES);
+    float* kexp = reinterpret_cast<float*>(out + NB16_BYTES);
     const int sizes[7] = {128 * 105, 128 * 128, 128 * 128, 128 * 128, 128 * 164, 128 * 128, 3 * 128};
     int rc;
-    if ((rc = launch_layer_exp(w, sizes, 7, kexp, st))) return rc;
+    if ((rc = launch_layer_amax(w, sizes, 7, kexp, st))) return rc;
     auto launch = [&](const PackBwd16& d) {
         const int64_t n = (int64_t)d.NT * 2 * d.NK * 256;
         hipLaunchKernelGGL(pack_bwd16_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d, out);

@@ -12,11 +12,11 @@ KEYS = ['rays', 'near', 'far', 'dst_Rs', 'dst_Ts', 'cnl_gtfms', 'motion_weights_
         'cnl_bbox_min_xyz', 'cnl_bbox_scale_xyz', 'bgcolor']
 
 
-def _oracle_steps(state, fr, target, t_rand, iters, n_samples, lrs):
+def _oracle_steps(state, fr, target, t_rand, iters, n_samples):
     """The reference's iteration on the CPU in fp64: 0.2*MSE (trainer.py:97-113 without LPIPS), Adam with one group per
     tensor.  fp64 because the fp32 gradients of the reference arithmetic are themselves ~0.4 % noisy
-    (tests/test_grad_oracle.py::test_reference_gradient_noise_floor), and Adam's first steps amplify gradient noise
-    on small elements into whole step sizes."""
+    (tests/test_grad_oracle.py::test_reference_gradient_noise_floor).  Returns the losses, the gradients of the first
+    iteration and the parameters after every iteration."""
     from oracle import oracle
     from humannerf_amd.train import customized_lr_names
     from humannerf_amd.config import cfg
@@ -26,21 +26,33 @@ def _oracle_steps(state, fr, target, t_rand, iters, n_samples, lrs):
         hit = [n for n in customized_lr_names() if n in k]
         groups.append({'params': [p], 'lr': cfg.train['lr_' + hit[0]] if hit else cfg.train.lr, 'name': hit[0] if hit else k})
     opt = torch.optim.Adam(groups, lr=cfg.train.lr, betas=(0.9, 0.999))
-    losses = []
+    losses, after, g1 = [], [], None
     for it in iters:
         opt.zero_grad()
         out = oracle.render(params, fr, iter_val=float(it), N_samples=n_samples, t_rand=t_rand, dtype=torch.float64)
         loss = 0.2 * torch.mean((out['rgb'] - torch.from_numpy(target).double()) ** 2)
         loss.backward()
+        if g1 is None:
+            g1 = {k: v.grad.numpy().copy() for k, v in params.items()}
         opt.step()
         decay = 0.1 ** (it / (cfg.train.lrate_decay * 1000))
         for g in opt.param_groups:
             g['lr'] = cfg.train.get('lr_' + str(g['name']), cfg.train.lr) * decay
         losses.append(float(loss))
-    return losses, {k: v.detach().numpy() for k, v in params.items()}
+        after.append({k: v.detach().numpy().copy() for k, v in params.items()})
+    return losses, g1, after
 
 
-def test_two_optimizer_steps_match_oracle_adam(seeded_params):
+def test_optimizer_steps_match_oracle_adam(seeded_params):
+    """Forward on the HIP path, loss, backward through the hand-written kernels, GroupedAdam, learning-rate decay.
+
+    Pinned tightly: the parameters after the FIRST iteration (same start, so the only inputs are the gradients: Adam's
+    first step is lr * g / (|g| + eps) element by element) and the loss of the SECOND iteration, which is a function of
+    those parameters.  Not pinned element-wise beyond that: the landscape behind the 2^9 positional-encoding band is so
+    rough that the second gradient already differs by several per cent between two evaluations whose parameters agree
+    to 1e-7 (measured: pose-decoder updates of iteration 2 and 3 differ in most elements) -- a property of the
+    problem, not of the kernels; the moment arithmetic of later steps is pinned by
+    tests/test_host_cpu.py::test_grouped_adam_is_torch_adam_with_fewer_launches."""
     from humannerf_amd import scene
     from humannerf_amd.config import cfg
     from humannerf_amd.network import Network
@@ -63,39 +75,29 @@ def test_two_optimizer_steps_match_oracle_adam(seeded_params):
         batch = {k: torch.from_numpy(np.ascontiguousarray(fr[k])).to(dev) for k in KEYS}
         batch['target_rgbs'] = torch.from_numpy(target).to(dev)
         batch['t_rand'] = torch.from_numpy(t_rand).to(dev)
-        gpu_losses = [float(tr.train_step(batch)[0]) for _ in range(3)]
-        got = {k: v.detach().cpu().numpy() for k, v in net.state_dict().items()}
+        gpu_losses = [float(tr.train_step(batch)[0])]
+        got1 = {k: v.detach().cpu().numpy() for k, v in net.state_dict().items()}
+        gpu_losses += [float(tr.train_step(batch)[0]) for _ in range(2)]
         assert tr.iter == 30003
     finally:
         cfg.N_samples, cfg.perturb, cfg.train.lossweights.lpips = old
-    ref_losses, want = _oracle_steps(seeded_params, fr, target, t_rand, [30000, 30001, 30002], S,
-                                     None)
+    ref_losses, g1, after = _oracle_steps(seeded_params, fr, target, t_rand, [30000, 30001, 30002], S)
     print('losses gpu', gpu_losses, 'oracle', ref_losses)
-    # the loss of iteration k+1 is a function of the parameters iteration k produced: pins forward, backward and update.
-    # Adam's first steps move every element by ~lr whatever |g| is, so fp32 noise on the (many) elements whose gradient
-    # is near zero turns into full-size steps of arbitrary sign: the losses drift apart geometrically
-    # (measured 1e-7, 3e-5, 6e-4), which is a property of Adam, not of the kernels
     for (a, b), tol in zip(zip(gpu_losses, ref_losses), (1e-5, 2e-4, 3e-3)):
         assert abs(a - b) <= tol * abs(b), (gpu_losses, ref_losses)
     assert ref_losses[2] < ref_losses[0] and gpu_losses[2] < gpu_losses[0]
-    # the parameters themselves.  Adam's first steps are sign-like (|update| ~ lr whatever |g| is): an element whose
-    # gradient is within fp32 noise of zero may legitimately move the other way, by at most ~2 lr per step -- so the
-    # bound on single elements is the step size, and what is pinned tightly is the bulk: relative L2 distance of the
-    # accumulated update, and the fraction of elements that moved differently
-    worst, worst_frac = (0.0, None), (0.0, None)
-    for k in want:
+    worst = (0.0, None)
+    for k, want in after[0].items():
         lr = 5e-5 if any(n in k for n in ('mweight_vol_decoder', 'pose_decoder', 'non_rigid_mlp')) else 5e-4
-        before = seeded_params[k]
-        du_ref, du = want[k] - before, got[k] - before
+        du_ref, du = want - seeded_params[k], got1[k] - seeded_params[k]
         diff = np.abs(du - du_ref)
-        assert diff.max() <= 3 * 2.05 * lr, (k, diff.max())
-        moved = np.abs(du_ref) > 0.5 * lr
-        if moved.sum() > 100:
-            frac_off = float((diff[moved] > 0.05 * lr).mean())
-            rel_l2 = float(np.linalg.norm((du - du_ref)[moved]) / np.linalg.norm(du_ref[moved]))
-            worst, worst_frac = max(worst, (rel_l2, k)), max(worst_frac, (frac_off, k))
-    print('3-step update vs fp64 oracle: worst relative L2 distance', worst, 'worst fraction of elements off by > 5 % of lr', worst_frac)
-    assert worst_frac[0] <= 0.1 and worst[0] <= 0.3, (worst, worst_frac)
+        assert diff.max() <= 2.05 * lr, (k, diff.max())                     # nobody moves further than a step apart
+        sure = np.abs(g1[k]) > 1e-5 * max(1e-30, np.abs(g1[k]).max())         # gradient well above noise and above eps
+        if sure.any():
+            worst = max(worst, (float(diff[sure].max() / lr), k))
+            assert diff[sure].max() <= 2e-2 * lr, (k, float(diff[sure].max() / lr))
+        # float32 parameters: the stored update is quantised to the parameter's ulp
+    print('first Adam step vs fp64 oracle: worst |update difference| / lr on elements with a sure gradient', worst)
 
 
 def test_train_loop_checkpoints_and_progress(tmp_path, seeded_params):
@@ -135,3 +137,41 @@ def test_train_loop_checkpoints_and_progress(tmp_path, seeded_params):
         assert len(st) == len(list(net.parameters())) and float(st[0]['step']) == 1.0
     finally:
         cfg.N_samples, cfg.perturb, cfg.train.lossweights.lpips, cfg.train.log_interval = old
+
+
+def test_operand_range_guard_raises_in_training(seeded_params):
+    """the f16 / split-f16 training arithmetic assumes activations inside f16's useful range.  A network
+    with a dead-small hidden layer (weights and bias ~1e-6) must not train silently on garbage weight gradients: the guard
+    flags it on the first checked backward pass and the next one raises, naming the remedy."""
+    from humannerf_amd import _lib, autograd, scene
+    from humannerf_amd.config import cfg
+    from humannerf_amd.network import Network
+    from humannerf_amd.train import Trainer
+    dev = torch.device('cuda:0')
+    fr = scene.synthetic_frame(H=512, W=512, focal_at_512=1250.0, ray_stride=61)
+    R = fr['rays'].shape[1]
+    old = (cfg.N_samples, cfg.train.lossweights.lpips, cfg.amd.train_check_every)
+    cfg.N_samples, cfg.train.lossweights.lpips, cfg.amd.train_check_every = 32, 0.0, 1
+    autograd.range_guard.calls, autograd.range_guard.pending = 0, []
+    try:
+        state = dict(seeded_params)
+        for k in ('cnl_mlp.module.pts_linears.6.weight', 'cnl_mlp.module.pts_linears.6.bias'):
+            state[k] = state[k] * np.float32(1e-5)
+        net = Network()
+        net.load_state_dict({k: torch.from_numpy(v) for k, v in state.items()})
+        tr = Trainer(net.to(dev))
+        batch = {k: torch.from_numpy(np.ascontiguousarray(fr[k])).to(dev) for k in KEYS}
+        batch['target_rgbs'] = torch.rand(R, 3, device=dev)
+        tr.train_step(batch)                       # flagged here ...
+        torch.cuda.synchronize()
+        with pytest.raises(_lib.HnrfError, match="below 2\\^-8"):
+            tr.train_step(batch)                   # ... raised here
+        # the exact kernels are not subject to it
+        cfg.amd.train_mlp_mode = cfg.amd.train_chain_mode = cfg.amd.train_dw_mode = 'f32'
+        autograd.range_guard.calls, autograd.range_guard.pending = 0, []
+        tr.train_step(batch)
+        tr.train_step(batch)
+    finally:
+        cfg.N_samples, cfg.train.lossweights.lpips, cfg.amd.train_check_every = old
+        cfg.amd.train_mlp_mode = cfg.amd.train_chain_mode = cfg.amd.train_dw_mode = 'f16x3'
+        autograd.range_guard.calls, autograd.range_guard.pending = 0, []
