@@ -228,7 +228,7 @@ def main():
         result['other_mode'] = {'mlp_mode': other, 'rays_per_s_per_gpu': round(R * 2 / dt_o, 1),
                                 'canonical_kernel_tflops': round(ach_o, 2), 'peak': PEAK_TFLOPS[other],
                                 'frac': round(ach_o / PEAK_TFLOPS[other], 4)}
-        result['precision'] = ('both modes pass the same fp32 parity tests against the reference (|d rgb| <= 5e-5); '
+        result['precision'] = ('both modes pass the same fp32 parity tests against the reference (12 golden cases, |d rgb|, |d alpha| <= 2e-5); '
                                'canonical-MLP error vs fp64: f16x3 4.5e-7, f32-MFMA 9e-7, torch-CPU fp32 5e-7 (relative)')
 
         # opt-in sample culling (cfg.amd.cull_eps = 1e-9: bound 2*S*eps = 2.6e-7 on rgb/alpha, ~100x below
@@ -305,27 +305,48 @@ def main():
         tb['near'], tb['far'] = data['near'][idx].contiguous(), data['far'][idx].contiguous()
         tb['target_rgbs'] = torch.from_numpy(np.random.RandomState(3 + rank).rand(idx.numel(), 3).astype(np.float32)).to(dev)
         trainer = Trainer(net, world_size=world, logdir=None)
-        for _ in range(3):
-            trainer.train_step(tb)               # warm-up (allocator growth, MIOpen solution search for the decoder)
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-        t0 = time.perf_counter()
-        for _ in range(args.train_steps):
-            loss, _ = trainer.train_step(tb)
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-        tt = time.perf_counter() - t0
-        if dist is not None:
-            t = torch.tensor([tt], device=dev, dtype=torch.float64)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            tt = float(t.item())
-        assert torch.isfinite(loss)
+
+        def timed_train(n):
+            for _ in range(3):
+                trainer.train_step(tb)           # warm-up (allocator growth, MIOpen solution search for the decoder)
+            torch.cuda.synchronize()
+            if dist is not None:
+                dist.barrier()
+            t0 = time.perf_counter()
+            for _ in range(n):
+                loss, _ = trainer.train_step(tb)
+            torch.cuda.synchronize()
+            if dist is not None:
+                dist.barrier()
+            tt = time.perf_counter() - t0
+            if dist is not None:
+                t = torch.tensor([tt], device=dev, dtype=torch.float64)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                tt = float(t.item())
+            assert torch.isfinite(loss)
+            return tt
+        tt = timed_train(args.train_steps)
+        # the same step with the weight-gradient operands stored in fp32 and multiplied as 22-bit split values
+        cfg.amd.train_operands = 'f32'
+        tt32 = timed_train(max(3, args.train_steps // 2)) / max(3, args.train_steps // 2)
+        cfg.amd.train_operands = 'f16'
         result['train'] = {'iters_per_s': round(args.train_steps / tt, 3), 'ms_per_iter': round(tt / args.train_steps * 1e3, 2),
                            'steps': args.train_steps, 'rays_per_iter_per_gpu': int(idx.numel()), 'samples_per_ray': S,
-                           'frames_per_iter': world, 'mlp_arithmetic': 'forward, dX chains and dW on split-f16 MFMA (fp32-equivalent; PE blocks and heads of dW fp32); no library GEMM on the per-sample path',
-                           'loss': '0.2*MSE on rgb (LPIPS-VGG unavailable offline)',
+                           'frames_per_iter': world,
+                           'mlp_arithmetic': 'forward and dX chains: split-f16 MFMA (22-bit operands, fp32 accumulate).  Weight '
+                                             'gradients: activations and dZ travel between the kernels as f16 (11-bit operands, power-of-two '
+                                             'scaled, one f16 MFMA per product through transposed LDS reads), fp32 accumulation over the '
+                                             '786 432 samples.  Gradients of all 55 tensors vs an fp64 evaluation: norm error <= 7.4e-4, '
+                                             'cosine >= 0.9999954 -- the same as with fp32 operands and with exact fp32 MFMA kernels '
+                                             '(tests/test_gpu_grad.py); the reference\'s own fp32 gradients are 4.4e-3 / 0.99999 from fp64.  '
+                                             'No library GEMM on the per-sample path',
+                           'with_fp32_operands': {'ms_per_iter': round(tt32 * 1e3, 2), 'iters_per_s': round(1.0 / tt32, 3),
+                                                  'note': "cfg.amd.train_operands = 'f32': activations / dZ stored fp32, 22-bit split "
+                                                          'operands in the weight-gradient kernels'},
+                           'gradient_sync': ('none (1 rank)' if world == 1 else
+                                             '2 collectives of 3.3 MB per step (volume-gradient all-reduce in front of the decoder '
+                                             'backward + one bucket), the decoder\'s 254 MB of gradients never travel'),
+                           'loss': '0.2*MSE on rgb: MSE-ONLY objective (LPIPS-VGG weights cannot be fetched offline)',
                            'note': 'reference DataParallel trains 1 frame/iter at any GPU count; here N ranks = N frames/iter'}
         net.eval()
         cfg.perturb = 0.

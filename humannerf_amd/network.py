@@ -239,8 +239,36 @@ def rodrigues(rvec):
                         x * z * oc - y * s, y * z * oc + x * s, z * z + (1. - z * z) * c), dim=1).view(-1, 3, 3)
 
 
+class _MotionBasis(torch.autograd.Function):
+    """MotionBasisComputer.forward (network_util.py:125-156) and its backward on libhnrf's single-wave kernels
+    (hnrf_motion_basis_fwd / _bwd) instead of ~120 tiny PyTorch launches per training step."""
+
+    @staticmethod
+    def forward(ctx, dst_Rs, dst_Ts, cnl_gtfms):
+        dst_Rs, dst_Ts, cnl_gtfms = dst_Rs.contiguous(), dst_Ts.contiguous(), cnl_gtfms.contiguous()
+        need = dst_Rs.requires_grad or dst_Ts.requires_grad
+        Rs, Ts, saved = ops.motion_basis_fwd(dst_Rs, dst_Ts, cnl_gtfms, want_saved=need)
+        if need:
+            ctx.save_for_backward(dst_Rs, dst_Ts, cnl_gtfms, saved)
+        return Rs, Ts
+
+    @staticmethod
+    def backward(ctx, g_Rs, g_Ts):
+        dst_Rs, dst_Ts, cnl_gtfms, saved = ctx.saved_tensors
+        d_Rs, d_Ts = ops.motion_basis_bwd(g_Rs.contiguous(), g_Ts.contiguous(), dst_Rs, dst_Ts, cnl_gtfms, saved)
+        return d_Rs, d_Ts, None
+
+
 def motion_basis(dst_Rs, dst_Ts, cnl_gtfms):
-    """MotionBasisComputer.forward (network_util.py:125-156) for one frame:
+    """MotionBasisComputer.forward for one frame: (B,3,3),(B,3),(B,4,4) -> (B,3,3),(B,3).  On the GPU: the fused kernel;
+    the torch restatement below it serves CPU-side checks only."""
+    if dst_Rs.is_cuda and dst_Rs.shape[0] == 24:
+        return _MotionBasis.apply(dst_Rs, dst_Ts, cnl_gtfms)
+    return motion_basis_torch(dst_Rs, dst_Ts, cnl_gtfms)
+
+
+def motion_basis_torch(dst_Rs, dst_Ts, cnl_gtfms):
+    """MotionBasisComputer.forward (network_util.py:125-156) for one frame in plain torch ops:
     (B,3,3),(B,3),(B,4,4) -> (B,3,3),(B,3)."""
     B = dst_Rs.shape[0]
     G = torch.zeros(B, 4, 4, dtype=dst_Rs.dtype, device=dst_Rs.device)

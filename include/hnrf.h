@@ -210,6 +210,18 @@ int hnrf_sample_warp_bwd(const float* rays_o, const float* rays_d, const float* 
                          int64_t R, int S, int B, int G,
                          float* d_vol, float* d_Rs, float* d_Ts, void* stream);
 
+/* Per-frame kinematics: MotionBasisComputer.forward (core/utils/network_util.py:125-156) and its backward as one
+ * single-wave kernel each (in PyTorch: 23 dependent 4x4 matmuls, a batched inverse and their autograd twins).
+ *  dst_Rs [24,3,3], dst_Ts [24,3], cnl_gtfms [24,4,4] -> Rs [24,3,3], Ts [24,3] = (cnl_gtfms_i A_i^-1)[:3,:3 | :3,3],
+ *  A_i = A_parent(i) [R_i | T_i] along the SMPL tree; fp64 internally.  saved (nullable): hnrf_motion_basis_saved_bytes()
+ *  bytes, 8-byte aligned, for the backward.  B must be 24.
+ *  bwd: g_Rs, g_Ts (gradients at the outputs) -> d_dst_Rs [24,3,3], d_dst_Ts [24,3]. */
+size_t hnrf_motion_basis_saved_bytes(void);
+int hnrf_motion_basis_fwd(const float* dst_Rs, const float* dst_Ts, const float* cnl_gtfms, int B, float* Rs, float* Ts,
+                          void* saved, void* stream);
+int hnrf_motion_basis_bwd(const float* g_Rs, const float* g_Ts, const float* dst_Rs, const float* dst_Ts,
+                          const float* cnl_gtfms, int B, const void* saved, float* d_dst_Rs, float* d_dst_Ts, void* stream);
+
 /* Weight / bias gradient of one nn.Linear inside the two MLPs (autograd of the Linear layers of
  * canonical_mlps/mlp_rgb_sigma.py and non_rigid_motion_mlps/mlp_offset.py under trainer.py:139-170):
  *   dW[o][i] = sum_s dZ[s][o] X[s][i]  for o < n_out, i < n_in;   db[o] = sum_s dZ[s][o]  (db may be NULL).
