@@ -48,6 +48,8 @@ SIGNATURES = {
     'hnrf_gen_rays_workspace_bytes': (_sz, [_int, _int]),
     'hnrf_gen_rays': (_int, [_vp] * 5 + [_int, _int] + [_vp] * 7 + [_sz, _vp]),
     'hnrf_render_workspace_bytes': (_sz, [_i64, _int]),
+    'hnrf_render_frame_workspace_bytes': (_sz, [_i64, _int]),
+    'hnrf_render_frame_fwd': (_int, [_vp] * 14 + [_int, ctypes.c_float, _i64, _int, _int, _int, _i64, _vp, _sz] + [_vp] * 11 + [_vp, _vp, _vp, _vp]),
     'hnrf_render_term_workspace_bytes': (_sz, [_i64, _int]),
     'hnrf_render_rays_term_fwd': (_int, [_vp] * 14 + [_int, ctypes.c_float, ctypes.c_float, _i64, _int, _int, _int, _vp, _sz, _vp, _vp, _vp, _vp, _vp]),
     'hnrf_render_rays_fwd': (_int, [_vp] * 14 + [_int, ctypes.c_float, _i64, _int, _int, _int, _vp, _sz, _vp, _vp, _vp, _vp, _vp, _vp]),

@@ -79,19 +79,26 @@ class OperandRangeGuard:
         self.pending = []
 
     @staticmethod
-    def flags(acts_list, d_in):
-        """device bool tensor [too_small, too_large, non_finite_gradient]"""
+    def flags(acts_list, d_in, dz_list=()):
+        """device bool tensor [too_small, too_large, non_finite_gradient]; dz_list: f16 dZ buffers of the chains (their
+        scaled values must stay below the f16 limit: the chain clamps there)"""
         amax = torch.cat([a.abs().amax(dim=(1, 2)).float() for a in acts_list if a is not None])
+        large = (amax >= ACT_MAX).any()
+        for dz in dz_list:
+            if dz is not None and dz.dtype == torch.float16:
+                large = large | (dz.abs().amax().float() >= ACT_MAX)
         fin = torch.isfinite(d_in).all()
-        return torch.stack([(amax < ACT_MIN).any(), (amax >= ACT_MAX).any(), ~fin])
+        return torch.stack([(amax < ACT_MIN).any(), large, ~fin])
 
-    def maybe_check(self, acts_list, d_in):
+    def due(self):
         every = int(amd_option('train_check_every', 200))
-        self.calls += 1
+        return every > 0 and (self.calls - 1) % every == 0
+
+    def maybe_check(self, acts_list, d_in, dz_list=()):
         self.poll()
-        if every <= 0 or (self.calls - 1) % every:
+        if not self.due():
             return
-        fl = self.flags(acts_list, d_in)
+        fl = self.flags(acts_list, d_in, dz_list)
         host = torch.empty(3, dtype=torch.bool, pin_memory=True)
         host.copy_(fl, non_blocking=True)
         ev = torch.cuda.Event()
@@ -113,7 +120,7 @@ class OperandRangeGuard:
                     'training operands left the range of the split-f16 arithmetic at backward pass %d: %s.  Set '
                     "cfg.amd.train_mlp_mode = train_chain_mode = train_dw_mode = 'f32' for this model." % (
                         call, ', '.join(n for n, f in (('a layer with all activations below 2^-8', small),
-                                                       ('activations at the f16 limit (clamped)', large),
+                                                       ('activations or scaled gradients at the f16 limit (clamped)', large),
                                                        ('non-finite incoming gradient', nonfinite)) if f)))
         self.pending = keep
 
@@ -182,8 +189,9 @@ class RenderRays(torch.autograd.Function):
         # canonical MLP (skip layer 5 takes [PE63 | h]): dX chain with the PE backward fused, then the weight gradients
         d_raw = d_raw.view(P, 4)
         _, chain_mode, dw_mode, _ = training_modes()
-        if chain_mode != 'f32' or dw_mode != 'f32':
-            range_guard.maybe_check([acts_c, acts_n], d_raw)
+        guard = chain_mode != 'f32' or dw_mode != 'f32'
+        if guard:
+            range_guard.calls += 1
         if ctx.half:
             dZc, d_xyz, sc_c = ops.canonical_bwd(xyz.reshape(P, 3), d_raw, bits_c, cn_w, 'f16x3h')
             gWc, gbc = _weight_grads_h(dZc, sc_c, acts_c, pe_c, d_raw, cn_w, skip_layer=5, skip_order='pe_first', npe=63)
@@ -191,7 +199,9 @@ class RenderRays(torch.autograd.Function):
             dZc, d_xyz, amax_c = ops.canonical_bwd(xyz.reshape(P, 3), d_raw, bits_c, cn_w, chain_mode)
             gWc, gbc = _weight_grads(dZc, acts_c, pe_c, d_raw, cn_w, skip_layer=5, skip_order='pe_first', amax=amax_c,
                                      mode=dw_mode)
+        dZc_keep = dZc if (guard and range_guard.due()) else None
         del dZc
+        dZn_keep = None
         if ctx.use_nonrigid:
             # xyz = x_skel + offset; layer 0 input [cond69 | PE36], skip layer 4 takes [h | PE36]
             if ctx.half:
@@ -201,11 +211,16 @@ class RenderRays(torch.autograd.Function):
                 dZn, d_x_skel, amax_n = ops.nonrigid_bwd(x_skel.reshape(P, 3), hann_w, d_xyz, bits_n, nr_w, chain_mode)
                 gWn, gbn = _weight_grads(dZn, acts_n, pe_n, d_xyz, nr_w, skip_layer=4, skip_order='h_first', amax=amax_n,
                                          mode=dw_mode)
+            dZn_keep = dZn if (guard and range_guard.due()) else None
+            del dZn
             # condition-code columns of layer 0: the same vector for every sample
             gWn[0] = torch.cat([gbn[0][:, None] * cond.reshape(1, -1), gWn[0]], dim=1)
         else:
             gWn, gbn = [None] * 7, [None] * 7
             d_x_skel = d_xyz
+        if guard:           # (before the dZ buffers are released)
+            range_guard.maybe_check([acts_c, acts_n], d_raw, [dZc_keep, dZn_keep])
+        del dZc_keep, dZn_keep
         d_vol, d_Rs, d_Ts = ops.sample_warp_bwd(rays_o, rays_d, z, motion_Rs, motion_Ts, vol, bbox_min, bbox_scale,
                                                 x_skel, mask, d_x_skel.view_as(x_skel).contiguous(), d_mask)
         return (None,) * 13 + (d_Rs, d_Ts, d_vol, *gWn, *gbn, *gWc, *gbc)

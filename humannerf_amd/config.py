@@ -146,6 +146,11 @@ _DEFAULTS = {
         # lean rendering only: stop evaluating a ray once its transmittance is below this (front-to-back slabs of 32
         # samples); bounds |d rgb|, |d alpha| by term_eps.  0 = off (the reference evaluates every sample).
         'term_eps': 0.0,
+        # rendering: run the LBS warp (K1) of ray chunk i+1 on a side stream while the MLP kernels of chunk i occupy
+        # the main one (ordering by events inside hnrf_render_frame_fwd, no host synchronisation).  Measured on the
+        # 512x512x128 frame: 91.5 ms with and without it -- the MLP kernels are power-limited, so whatever K1 draws
+        # beside them they lose; off by default
+        'overlap_warp': False,
         # multi-GPU training: 'volume' = average the 3.3 MB weight-volume gradient in front of the decoder backward (the
         # decoder's 254 MB of gradients never travel; needs the same priors on every rank, verified at run time),
         # 'full' = plain all-reduce of every gradient

@@ -478,32 +478,30 @@ class Network(nn.Module):
             t_rand = None
         diag = bool(amd_option('diagnostics', True))
 
-        chunks = []
-        full = None
-        if not train_path and diag and N > int(cfg.chunk):
-            # whole-frame buffers for the 11 outputs: every chunk's kernels write their row range directly
-            # (the reference concatenates the per-chunk results, network.py:343-350: one more pass over 17 KB per ray)
-            B = motion_Rs.shape[0]
-            shp = {'rgb': (3,), 'alpha': (), 'depth': (), 'weights_on_rays': (S,), 'rgb_on_rays': (S, 3), 'cnl_xyz': (3,),
-                   'cnl_rgb': (3,), 'cnl_weight': (), 'xyz_on_rays': (S, 3), 'backward_motion_weights': (S, B),
-                   'offsets': (S, 3)}
-            full = {k: torch.empty((N,) + v, device=dev) for k, v in shp.items()}
-        for i in range(0, N, int(cfg.chunk)):                              # network.py:333
-            sl = slice(i, min(i + int(cfg.chunk), N))
-            if train_path:
-                chunks.append(self._render_rays_train(rays_o[sl], rays_d[sl], near[sl], far[sl],
-                                                      None if t_rand is None else t_rand[sl], motion_Rs, motion_Ts,
-                                                      vol, bbox_min, bbox_scale, hann_w, cond, bg, S, not ignore_nr,
-                                                      diag))
-                continue
-            chunks.append(self._render_rays(rays_o[sl], rays_d[sl], near[sl], far[sl],
-                                            None if t_rand is None else t_rand[sl],
-                                            motion_Rs, motion_Ts, vol, bbox_min, bbox_scale, hann_w,
-                                            nr_packed, cnl_packed, bg, S, mode, diag,
-                                            None if full is None else {k: v[sl] for k, v in full.items()}))
-        if full is not None:
-            out = full
+        term_eps = float(amd_option('term_eps', 0.0))
+        if not train_path and term_eps == 0.0:
+            # the whole frame in one library call: chunk loop of network.py:330-352, results straight into whole-frame
+            # tensors (the reference concatenates per-chunk results: one more pass over 17 KB per ray); optionally K1 of
+            # the next chunk on a side stream under the MLP kernels of the current one (cfg.amd.overlap_warp)
+            out, self._workspace = ops.render_frame(
+                rays_o, rays_d, near, far, t_rand, motion_Rs, motion_Ts, vol, bbox_min, bbox_scale, hann_w, nr_packed,
+                cnl_packed, bg, S, int(cfg.chunk), mode, diagnostics=diag,
+                cull_eps=0.0 if diag else float(amd_option('cull_eps', 0.0)), workspace=self._workspace,
+                overlap=bool(amd_option('overlap_warp', False)), mlp_event_log=self.mlp_event_log)
         else:
+            chunks = []
+            for i in range(0, N, int(cfg.chunk)):                          # network.py:333
+                sl = slice(i, min(i + int(cfg.chunk), N))
+                if train_path:
+                    chunks.append(self._render_rays_train(rays_o[sl], rays_d[sl], near[sl], far[sl],
+                                                          None if t_rand is None else t_rand[sl], motion_Rs, motion_Ts,
+                                                          vol, bbox_min, bbox_scale, hann_w, cond, bg, S, not ignore_nr,
+                                                          diag))
+                    continue
+                chunks.append(self._render_rays(rays_o[sl], rays_d[sl], near[sl], far[sl],
+                                                None if t_rand is None else t_rand[sl],
+                                                motion_Rs, motion_Ts, vol, bbox_min, bbox_scale, hann_w,
+                                                nr_packed, cnl_packed, bg, S, mode, diag, None))
             out = {k: (torch.cat([c[k] for c in chunks], 0) if len(chunks) > 1 else chunks[0][k]) for k in chunks[0]}
         lead = list(rays_shape[:-1])
         return {k: v.reshape(lead + list(v.shape[1:])) for k, v in out.items()}

@@ -202,6 +202,74 @@ def render_rays(rays_o, rays_d, near, far, t_rand, motion_Rs, motion_Ts, vol, bb
     return out
 
 
+_frame_ctx = {}
+
+
+def _frame_streams(device):
+    """Per-device side stream + the 5 events hnrf_render_frame_fwd orders the two streams with."""
+    ctx = _frame_ctx.get(device.index)
+    if ctx is None:
+        side = torch.cuda.Stream(device=device)
+        evs = [torch.cuda.Event() for _ in range(5)]
+        for e in evs:
+            e.record()                       # forces creation of the hipEvent_t
+        ctx = _frame_ctx[device.index] = (side, evs)
+    return ctx
+
+
+def render_frame(rays_o, rays_d, near, far, t_rand, motion_Rs, motion_Ts, vol, bbox_min, bbox_scale, hann_w, nr_packed,
+                 cnl_packed, bgcolor, n_samples, chunk, mode='f16x3', diagnostics=True, cull_eps=0.0, workspace=None,
+                 overlap=True, mlp_event_log=None):
+    """The whole frame in one call (hnrf_render_frame_fwd): all ray chunks through K1..K4, results in whole-frame tensors;
+    K1 of the next chunk on a side stream while the MLP kernels of the current one run.  Returns (dict of outputs,
+    workspace).  ``mlp_event_log``: list that receives one (start, stop) torch.cuda.Event pair per chunk."""
+    lib = _lib.load()
+    near, far = near.reshape(-1), far.reshape(-1)
+    _chk(rays_o, rays_d, near, far, t_rand, motion_Rs, motion_Ts, vol, bbox_min, bbox_scale, hann_w, nr_packed, cnl_packed,
+         bgcolor)
+    N, S, B, G = rays_o.shape[0], int(n_samples), motion_Rs.shape[0], vol.shape[-1]
+    dev = rays_o.device
+    chunk = int(chunk)
+    need = lib.hnrf_render_frame_workspace_bytes(min(chunk, max(N, 1)), S)
+    if workspace is None or workspace.numel() * 4 < need or workspace.device != dev:
+        workspace = torch.empty(need // 4 + 64, device=dev)
+    shp = {'rgb': (3,), 'alpha': (), 'depth': ()}
+    if diagnostics:
+        shp.update(weights_on_rays=(S,), rgb_on_rays=(S, 3), cnl_xyz=(3,), cnl_rgb=(3,), cnl_weight=(), xyz_on_rays=(S, 3),
+                   backward_motion_weights=(S, B), offsets=(S, 3))
+    out = {k: torch.empty((N,) + v, device=dev) for k, v in shp.items()}
+    g = lambda k: _ptr(out.get(k))
+    side, evs, ev_arr = None, None, None
+    if overlap and N > chunk:
+        side, evs = _frame_streams(dev)
+        ev_arr = (ctypes.c_void_p * 5)(*[e.cuda_event for e in evs])
+    mlp_arr, pairs = None, []
+    if mlp_event_log is not None:
+        nchunk = (N + chunk - 1) // chunk
+        pairs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(nchunk)]
+        for a, b in pairs:
+            a.record()
+            b.record()
+        mlp_arr = (ctypes.c_void_p * (2 * nchunk))(*[e.cuda_event for p in pairs for e in p])
+    _lib.check(lib.hnrf_render_frame_fwd(
+        _ptr(rays_o), _ptr(rays_d), _ptr(near), _ptr(far), _ptr(t_rand), _ptr(motion_Rs), _ptr(motion_Ts), _ptr(vol),
+        _ptr(bbox_min), _ptr(bbox_scale), _ptr(hann_w), _ptr(nr_packed), _ptr(cnl_packed), _ptr(bgcolor), MLP_MODES[mode],
+        float(cull_eps), N, S, B, G, chunk, _ptr(workspace), workspace.numel() * 4, g('rgb'), g('alpha'), g('depth'),
+        g('weights_on_rays'), g('rgb_on_rays'), g('cnl_xyz'), g('cnl_rgb'), g('cnl_weight'), g('xyz_on_rays'),
+        g('backward_motion_weights'), g('offsets'), side.cuda_stream if side is not None else None, ev_arr, mlp_arr,
+        _stream()), 'hnrf_render_frame_fwd')
+    if side is not None:
+        # the side stream read the inputs and wrote backward_motion_weights / the workspace: keep the allocator from
+        # handing those blocks out again before it is done (everything it did is also ordered on the main stream)
+        for t in (rays_o, rays_d, near, far, t_rand, motion_Rs, motion_Ts, vol, bbox_min, bbox_scale, workspace,
+                  out.get('backward_motion_weights')):
+            if t is not None:
+                t.record_stream(side)
+    if mlp_event_log is not None:
+        mlp_event_log.extend(pairs)
+    return out, workspace
+
+
 def render_rays_term(rays_o, rays_d, near, far, t_rand, motion_Rs, motion_Ts, vol, bbox_min, bbox_scale,
                      hann_w, nr_packed, cnl_packed, bgcolor, n_samples, mode='f16x3', term_eps=1e-4, cull_eps=0.0,
                      workspace=None, want_count=False):

@@ -167,6 +167,27 @@ int hnrf_render_rays_term_fwd(const float* rays_o, const float* rays_d,
                               void* workspace, size_t workspace_bytes,
                               float* rgb, float* alpha, float* depth, int* evaluated, void* stream);
 
+/* Whole frame: Network._batchify_rays (network.py:330-352) over _render_rays.  N rays in chunks of `chunk` (cfg.chunk)
+ * through K1..K4, rgb [N,3] / alpha [N] / depth [N] written for the whole frame.  The eight diagnostic outputs of the
+ * reference's forward are optional, all or none (whole-frame buffers: weights_on_rays [N,S], rgb_on_rays [N,S,3],
+ * cnl_xyz [N,3], cnl_rgb [N,3], cnl_weight [N], xyz_on_rays [N,S,3], bmw [N,S,B], offsets [N,S,3]); sample culling
+ * (cull_eps > 0) only without them.  workspace: hnrf_render_frame_workspace_bytes(chunk, S), 256-byte aligned (two chunk
+ * workspaces that alternate).
+ * side_stream (nullable): a second stream of the same device on which the LBS warp (K1) of chunk i+1 runs while the
+ * MLP kernels of chunk i occupy `stream` -- K1 has no LDS and few registers, so it shares the CUs with them.  Needs
+ * events = 5 hipEvent_t owned by the caller (no timing needed); all ordering between the two streams is expressed
+ * through them, nothing is synchronised with the host.  On return every result is ordered on `stream`.
+ * mlp_events (nullable): 2 x ceil(N / chunk) hipEvent_t recorded around every canonical-MLP launch (for timing). */
+size_t hnrf_render_frame_workspace_bytes(int64_t chunk, int S);
+int hnrf_render_frame_fwd(const float* rays_o, const float* rays_d, const float* near, const float* far,
+                          const float* t_rand, const float* motion_Rs, const float* motion_Ts, const float* vol,
+                          const float* bbox_min, const float* bbox_scale, const float* hann_w, const void* nr_packed,
+                          const void* cnl_packed, const float* bgcolor, int mode, float cull_eps, int64_t N, int S,
+                          int B, int G, int64_t chunk, void* workspace, size_t workspace_bytes, float* rgb, float* alpha,
+                          float* depth, float* weights_on_rays, float* rgb_on_rays, float* cnl_xyz, float* cnl_rgb,
+                          float* cnl_weight, float* xyz_on_rays, float* bmw, float* offsets, void* side_stream,
+                          void* const* events, void* const* mlp_events, void* stream);
+
 /* =============================== training (backward) ===============================
  * The reference trains through torch.autograd over the ops above (trainer.py:206-220).
  * Here: the forward runs the *_fwd_train variants (either arithmetic mode) which also save the

@@ -392,7 +392,7 @@ def test_network_gradients_match_oracle_autograd_in_other_branches(seeded_params
             assert got is None or float(got.norm()) <= 1e-12, name
             continue
         g, r = got.double().cpu().reshape(-1), ref.double().reshape(-1)
-        assert abs(float(g.norm()) - float(r.norm())) <= 2e-2 * float(r.norm()), name
+        assert abs(float(g.norm()) - float(r.norm())) <= 5e-2 * float(r.norm()), name
         assert float(g @ r / (g.norm() * r.norm())) >= 0.999, name
         checked += 1
     assert checked >= (40 if variant != 'tpose' else 26)

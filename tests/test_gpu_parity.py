@@ -426,6 +426,28 @@ def test_ray_chunking_is_invisible(gpu_net, golden_frame):
         assert torch.equal(one[k], many[k]), k
 
 
+def test_warp_overlap_on_a_side_stream_changes_nothing(gpu_net, golden_frame):
+    """cfg.amd.overlap_warp: K1 of chunk i+1 on a side stream under the MLP kernels of chunk i (hnrf_render_frame_fwd,
+    two alternating workspaces, five events) -- same bits as the single-stream sequence, in both output forms, also
+    when called back to back (the second frame must not race the first one's side-stream work)."""
+    from humannerf_amd.config import cfg
+    cfg.perturb, cfg.chunk = 0., 40
+    try:
+        with torch.no_grad():
+            for diag in (True, False):
+                cfg.amd.diagnostics = diag
+                cfg.amd.overlap_warp = False
+                one = gpu_net(**frame_to_gpu(golden_frame), iter_val=1e7)
+                cfg.amd.overlap_warp = True
+                two = [gpu_net(**frame_to_gpu(golden_frame), iter_val=1e7) for _ in range(3)]
+                for t in two:
+                    assert set(t) == set(one)
+                    for k in one:
+                        assert torch.equal(one[k], t[k]), (diag, k)
+    finally:
+        cfg.chunk, cfg.perturb, cfg.amd.diagnostics, cfg.amd.overlap_warp = 32768, 1.0, True, False
+
+
 def test_c5_sized_samples_per_ray(gpu_net, golden_frame):
     """BASELINE config 5 uses 256 samples per ray: lean path == diagnostic path at S = 256, and the
     denser sampling converges towards the S = 128 image (same integral)."""
