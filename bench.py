@@ -310,11 +310,17 @@ def main():
             for _ in range(3):
                 trainer.train_step(tb)           # warm-up (allocator growth, MIOpen solution search for the decoder)
             torch.cuda.synchronize()
-            if dist is not None:
+            if dist is not None:                 # ranks leave the warm-up at different times: line them up, run one more
+                dist.barrier()                   # untimed step together, line up again
+                trainer.train_step(tb)
+                torch.cuda.synchronize()
                 dist.barrier()
             t0 = time.perf_counter()
             for _ in range(n):
                 loss, _ = trainer.train_step(tb)
+                if os.environ.get('HNRF_BENCH_DEBUG') and rank == 0:
+                    torch.cuda.synchronize()
+                    print('train_step done at %.1f ms' % ((time.perf_counter() - t0) * 1e3), file=sys.stderr, flush=True)
             torch.cuda.synchronize()
             if dist is not None:
                 dist.barrier()

@@ -249,6 +249,37 @@ class Trainer:
         return self.load_state(ckpt)
 
 
+def make_progress_fn(frames, logdir, device=None, imgs_per_row=4):
+    """The reference's Trainer.progress (trainer.py:271-350) as a ``progress_fn`` for Trainer.train: renders ``frames``
+    (per-frame dicts like the 'progress' dataset yields: 16 frames in image mode, each with ``target_rgbs``) with the
+    current weights, puts render and truth side by side, tiles them and writes ``prog_{iter:06}.jpg`` into ``logdir``.
+    Returns True when a rendered image is empty (all background) during the first 5000 iterations, like the reference."""
+    import numpy as np
+    from . import render
+
+    def progress(trainer):
+        os.makedirs(logdir, exist_ok=True)
+        pairs, empty = {}, False
+
+        def on_image(i, rgb8, a8, t8=None):
+            pairs[i] = np.concatenate([rgb8, t8 if t8 is not None else a8], axis=1)
+
+        old_iter = cfg.get('eval_iter', None)
+        cfg.eval_iter = trainer.iter                                   # progress renders use the CURRENT iteration (trainer.py:293)
+        try:
+            imgs = render.render_frames(trainer.network, frames, device=device, on_image=on_image, show_truth=True)
+        finally:
+            cfg.eval_iter = old_iter
+        if trainer.iter <= 5000:
+            bg = np.array(cfg.bgcolor, dtype=np.float32)
+            empty = any(np.allclose(im, bg, atol=5.) for im in imgs.values())
+        from PIL import Image
+        tiled = render.tile_images([pairs[i] for i in sorted(pairs)], imgs_per_row=imgs_per_row)
+        Image.fromarray(tiled).save(os.path.join(logdir, 'prog_%06d.jpg' % trainer.iter))
+        return empty
+    return progress
+
+
 def load_checkpoint(path, map_location=None):
     """Read a ``.tar`` checkpoint of the reference's layout ({'iter', 'network', 'optimizer'}, trainer.py:356-364)
     without executing anything from the file (``weights_only=True``)."""

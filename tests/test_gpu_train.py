@@ -123,11 +123,21 @@ def test_train_loop_checkpoints_and_progress(tmp_path, seeded_params):
         batch['target_rgbs'] = torch.rand(R, 3, device=dev)
         seen, logs = [], []
 
+        from humannerf_amd.train import make_progress_fn
+        prog_frames = [scene.synthetic_frame(H=48, W=40, focal_at_512=1250.0, pose_seed=s) for s in range(5)]
+        for f in prog_frames:
+            f['target_rgbs'] = np.random.RandomState(1).rand(f['rays'].shape[1], 3).astype(np.float32)
+        write_mosaic = make_progress_fn(prog_frames, str(tmp_path), device=dev)
+
         def progress(t):
             assert not t.network.training and cfg.perturb == 0.
             seen.append(t.iter)
+            write_mosaic(t)
         tr.train([batch] * 10, maxiter=4, progress_fn=progress, log_fn=logs.append)
         assert tr.iter == 5 and seen == [1] and len(logs) == 2 and logs[0].startswith('Iter 2 ')
+        from PIL import Image
+        mosaic = np.asarray(Image.open(tmp_path / 'prog_000001.jpg'))
+        assert mosaic.shape == (48, 4 * 2 * 40, 3)                     # 5 frames, 4 per row: the incomplete row is dropped
         assert cfg.perturb == old[1]
         ck = load_checkpoint(str(tmp_path / 'latest.tar'))
         assert set(ck) == {'iter', 'network', 'optimizer'} and ck['iter'] == 1
