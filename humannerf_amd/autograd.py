@@ -8,6 +8,8 @@ holding the whole output), K1'.  No library GEMM is left on the per-sample path.
 bases, the weight volume and all MLP parameters -- exactly the tensors through which the
 reference's four parameter groups receive gradient (last row).
 """
+import math
+
 import torch
 
 from . import ops
@@ -82,11 +84,14 @@ class OperandRangeGuard:
     def flags(acts_list, d_in, dz_list=()):
         """device bool tensor [too_small, too_large, non_finite_gradient]; dz_list: f16 dZ buffers of the chains (their
         scaled values must stay below the f16 limit: the chain clamps there)"""
-        amax = torch.cat([a.abs().amax(dim=(1, 2)).float() for a in acts_list if a is not None])
+        def layer_amax(a):                           # two-stage: a reduction to L outputs alone runs on L workgroups
+            lo, hi = torch.aminmax(a.reshape(a.shape[0], math.gcd(a[0].numel(), 1024), -1), dim=2)
+            return torch.maximum(hi.amax(dim=1), -lo.amin(dim=1)).float()
+        amax = torch.cat([layer_amax(a) for a in acts_list if a is not None])
         large = (amax >= ACT_MAX).any()
         for dz in dz_list:
             if dz is not None and dz.dtype == torch.float16:
-                large = large | (dz.abs().amax().float() >= ACT_MAX)
+                large = large | (layer_amax(dz) >= ACT_MAX).any()
         fin = torch.isfinite(d_in).all()
         return torch.stack([(amax < ACT_MIN).any(), large, ~fin])
 

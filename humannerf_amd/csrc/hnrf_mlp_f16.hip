@@ -89,12 +89,18 @@ __host__ __device__ inline int layer_exponent(float amax) {
     return (ex < -8 || ex > 3) ? -2 - ex : 0;
 }
 
-// one thread per f16 PAIR of the weight image (slab = 2 NK KiB) + the layer's bias records
-__global__ void pack_layer16_kernel(PackLayer16 d, const float* __restrict__ cond, char* __restrict__ packed) {
+// one thread per f16 PAIR of the weight image (slab = 2 NK KiB) + the layer's bias records; blockIdx.y = layer: the
+// whole image of an MLP is ONE launch (16 + 18 launches of ~6 us per training step when every layer had its own)
+struct PackSet16 {
+    PackLayer16 d[9];
+};
+__global__ void pack_layer16_kernel(PackSet16 set, const float* __restrict__ cond, char* __restrict__ packed) {
+    const PackLayer16& d = set.d[blockIdx.y];
     const int NK = d.NKA + d.NKB;
     const int slab_units = 2 * NK * 256;                          // 4-byte units per slab
     const int64_t n = (int64_t)d.NT * slab_units;
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if ((int64_t)blockIdx.x * blockDim.x >= (n > d.NT * 32 ? n : (int64_t)d.NT * 32)) return;   // (grid sized for the largest layer)
     int kexp = 0;
     if (d.head_scale) {                                            // (<= 4 x 256 weights: every block finds the maximum itself)
         __shared__ float red[256];
@@ -1162,7 +1168,11 @@ __global__ __launch_bounds__(256) void layer_amax_kernel(LayerSet ls, float* __r
     if (threadIdx.x == 0) atomicMax(reinterpret_cast<unsigned int*>(out) + blockIdx.x, __float_as_uint(red[0]));
 }
 
-__global__ void pack_bwd16_kernel(PackBwd16 d, char* __restrict__ packed) {
+struct PackBwdSet16 {
+    PackBwd16 d[10];
+};
+__global__ void pack_bwd16_kernel(PackBwdSet16 set, char* __restrict__ packed) {
+    const PackBwd16& d = set.d[blockIdx.y];                       // blockIdx.y = stage: one launch per MLP image
     const int slab_units = 2 * d.NK * 256;
     const int64_t n = (int64_t)d.NT * slab_units;
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1466,9 +1476,16 @@ __global__ __launch_bounds__(256) void nonrigid_bwd16_kernel(const float* __rest
     }
 }
 
-static int launch_pack16(const PackLayer16& d, const float* cond, char* packed, hipStream_t st) {
-    const int64_t n = (int64_t)d.NT * (2 * (d.NKA + d.NKB) * 256);
-    hipLaunchKernelGGL(pack_layer16_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d, cond, packed);
+static int launch_pack16(const PackLayer16* ds, int count, const float* cond, char* packed, hipStream_t st) {
+    PackSet16 set{};
+    int64_t nmax = 0;
+    for (int i = 0; i < count; ++i) {
+        set.d[i] = ds[i];
+        const int64_t n = (int64_t)ds[i].NT * (2 * (ds[i].NKA + ds[i].NKB) * 256);
+        nmax = n > nmax ? n : nmax;
+    }
+    hipLaunchKernelGGL(pack_layer16_kernel, dim3((unsigned)((nmax + 255) / 256), (unsigned)count), dim3(256), 0, st, set, cond,
+                       packed);
     return check_launch("hnrf pack (f16x3)");
 }
 
@@ -1482,22 +1499,18 @@ int canonical16_pack(const float* const* w, const float* const* b, void* packed,
         set_error("hnrf_canonical_pack: memset failed");
         return HNRF_E_LAUNCH;
     }
-    PackLayer16 d{w[0], b[0], 256, 63, 8, 4, 0, PE16_CANONICAL, 0, 0, 0, CNL16_L0, CNL16_BIAS, 0};
-    if ((rc = launch_pack16(d, nullptr, out, st))) return rc;
-    for (int l = 1; l <= 4; ++l) {
-        d = PackLayer16{w[l], b[l], 256, 256, 8, 0, 16, PE16_NONE, 0, 0, 0,
-                        CNL16_L1 + (l - 1) * 8 * CNL16_NB_MID * KB, CNL16_BIAS + l * 1024, 0};
-        if ((rc = launch_pack16(d, nullptr, out, st))) return rc;
-    }
-    d = PackLayer16{w[5], b[5], 256, 319, 8, 4, 16, PE16_CANONICAL, 0, 63, 0, CNL16_L5, CNL16_BIAS + 5 * 1024, 0};
-    if ((rc = launch_pack16(d, nullptr, out, st))) return rc;
-    for (int l = 6; l <= 7; ++l) {
-        d = PackLayer16{w[l], b[l], 256, 256, 8, 0, 16, PE16_NONE, 0, 0, 0,
-                        CNL16_L6 + (l - 6) * 8 * CNL16_NB_MID * KB, CNL16_BIAS + l * 1024, 0};
-        if ((rc = launch_pack16(d, nullptr, out, st))) return rc;
-    }
-    d = PackLayer16{w[8], b[8], 4, 256, 1, 0, 16, PE16_NONE, 0, 0, 0, CNL16_OUT, CNL16_BIAS + 8 * 1024, 1};
-    return launch_pack16(d, nullptr, out, st);
+    (void)rc;
+    PackLayer16 d[9];
+    d[0] = PackLayer16{w[0], b[0], 256, 63, 8, 4, 0, PE16_CANONICAL, 0, 0, 0, CNL16_L0, CNL16_BIAS, 0};
+    for (int l = 1; l <= 4; ++l)
+        d[l] = PackLayer16{w[l], b[l], 256, 256, 8, 0, 16, PE16_NONE, 0, 0, 0,
+                           CNL16_L1 + (l - 1) * 8 * CNL16_NB_MID * KB, CNL16_BIAS + l * 1024, 0};
+    d[5] = PackLayer16{w[5], b[5], 256, 319, 8, 4, 16, PE16_CANONICAL, 0, 63, 0, CNL16_L5, CNL16_BIAS + 5 * 1024, 0};
+    for (int l = 6; l <= 7; ++l)
+        d[l] = PackLayer16{w[l], b[l], 256, 256, 8, 0, 16, PE16_NONE, 0, 0, 0,
+                           CNL16_L6 + (l - 6) * 8 * CNL16_NB_MID * KB, CNL16_BIAS + l * 1024, 0};
+    d[8] = PackLayer16{w[8], b[8], 4, 256, 1, 0, 16, PE16_NONE, 0, 0, 0, CNL16_OUT, CNL16_BIAS + 8 * 1024, 1};
+    return launch_pack16(d, 9, nullptr, out, st);
 }
 
 int nonrigid16_pack(const float* const* w, const float* const* b, const float* cond, void* packed, hipStream_t st) {
@@ -1507,20 +1520,17 @@ int nonrigid16_pack(const float* const* w, const float* const* b, const float* c
         set_error("hnrf_nonrigid_pack: memset failed");
         return HNRF_E_LAUNCH;
     }
-    PackLayer16 d{w[0], b[0], 128, 105, 4, 4, 0, PE16_NONRIGID, 69, 0, 69, NR16_L0, NR16_BIAS, 0};
-    if ((rc = launch_pack16(d, cond, out, st))) return rc;
-    for (int l = 1; l <= 3; ++l) {
-        d = PackLayer16{w[l], b[l], 128, 128, 4, 0, 8, PE16_NONE, 0, 0, 0,
-                        NR16_L1 + (l - 1) * 4 * NR16_NB_MID * KB, NR16_BIAS + l * 512, 0};
-        if ((rc = launch_pack16(d, cond, out, st))) return rc;
-    }
+    (void)rc;
+    PackLayer16 d[7];
+    d[0] = PackLayer16{w[0], b[0], 128, 105, 4, 4, 0, PE16_NONRIGID, 69, 0, 69, NR16_L0, NR16_BIAS, 0};
+    for (int l = 1; l <= 3; ++l)
+        d[l] = PackLayer16{w[l], b[l], 128, 128, 4, 0, 8, PE16_NONE, 0, 0, 0,
+                           NR16_L1 + (l - 1) * 4 * NR16_NB_MID * KB, NR16_BIAS + l * 512, 0};
     // W4 columns: [h(128) | PE36] (mlp_offset.py:81-82); our K order is [PE | h]
-    d = PackLayer16{w[4], b[4], 128, 164, 4, 4, 8, PE16_NONRIGID, 128, 0, 0, NR16_L4, NR16_BIAS + 4 * 512, 0};
-    if ((rc = launch_pack16(d, cond, out, st))) return rc;
-    d = PackLayer16{w[5], b[5], 128, 128, 4, 0, 8, PE16_NONE, 0, 0, 0, NR16_L5, NR16_BIAS + 5 * 512, 0};
-    if ((rc = launch_pack16(d, cond, out, st))) return rc;
-    d = PackLayer16{w[6], b[6], 3, 128, 1, 0, 8, PE16_NONE, 0, 0, 0, NR16_OUT, NR16_BIAS + 6 * 512, 1};
-    return launch_pack16(d, cond, out, st);
+    d[4] = PackLayer16{w[4], b[4], 128, 164, 4, 4, 8, PE16_NONRIGID, 128, 0, 0, NR16_L4, NR16_BIAS + 4 * 512, 0};
+    d[5] = PackLayer16{w[5], b[5], 128, 128, 4, 0, 8, PE16_NONE, 0, 0, 0, NR16_L5, NR16_BIAS + 5 * 512, 0};
+    d[6] = PackLayer16{w[6], b[6], 3, 128, 1, 0, 8, PE16_NONE, 0, 0, 0, NR16_OUT, NR16_BIAS + 6 * 512, 1};
+    return launch_pack16(d, 7, cond, out, st);
 }
 
 int canonical16_fwd(const float* xyz, const void* packed, int64_t P, float* raw, const int* idx, const int* count,
@@ -1594,25 +1604,33 @@ static int launch_layer_amax(const float* const* w, const int* n, int count, flo
     return check_launch("hnrf pack (layer maxima)");
 }
 
+static int launch_pack_bwd16(const PackBwd16* ds, int count, char* out, hipStream_t st) {
+    PackBwdSet16 set{};
+    int64_t nmax = 0;
+    for (int i = 0; i < count; ++i) {
+        set.d[i] = ds[i];
+        const int64_t n = (int64_t)ds[i].NT * 2 * ds[i].NK * 256;
+        nmax = n > nmax ? n : nmax;
+    }
+    hipLaunchKernelGGL(pack_bwd16_kernel, dim3((unsigned)((nmax + 255) / 256), (unsigned)count), dim3(256), 0, st, set, out);
+    return check_launch("hnrf pack (backward, f16x3)");
+}
+
 int canonical16_bwd_pack(const float* const* w, void* packed, hipStream_t st) {
     char* out = (char*)packed;
     float* kexp = reinterpret_cast<float*>(out + CB16_BYTES);
     const int sizes[9] = {256 * 63, 256 * 256, 256 * 256, 256 * 256, 256 * 256, 256 * 319, 256 * 256, 256 * 256, 4 * 256};
     int rc;
     if ((rc = launch_layer_amax(w, sizes, 9, kexp, st))) return rc;
-    auto launch = [&](const PackBwd16& d) {
-        const int64_t n = (int64_t)d.NT * 2 * d.NK * 256;
-        hipLaunchKernelGGL(pack_bwd16_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d, out);
-        return check_launch("hnrf pack (backward, f16x3)");
-    };
-    if ((rc = launch(PackBwd16{w[8], 4, 256, 8, 1, PE16_NONE, 0, 1, CB16_HEAD, kexp + 8}))) return rc;
-    for (int l = 7; l >= 6; --l)
-        if ((rc = launch(PackBwd16{w[l], 256, 256, 8, 16, PE16_NONE, 0, 0, CB16_L7 + (7 - l) * CB16_FULL, kexp + l}))) return rc;
-    if ((rc = launch(PackBwd16{w[5], 256, 319, 8, 16, PE16_NONE, 63, 0, CB16_L7 + 2 * CB16_FULL, kexp + 5}))) return rc;
-    if ((rc = launch(PackBwd16{w[5], 256, 319, 2, 16, PE16_CANONICAL, 0, 0, CB16_L5P, kexp + 5}))) return rc;
-    for (int l = 4; l >= 1; --l)
-        if ((rc = launch(PackBwd16{w[l], 256, 256, 8, 16, PE16_NONE, 0, 0, CB16_L4 + (4 - l) * CB16_FULL, kexp + l}))) return rc;
-    return launch(PackBwd16{w[0], 256, 63, 2, 16, PE16_CANONICAL, 0, 0, CB16_L0P, kexp});
+    PackBwd16 d[10];
+    int n = 0;
+    d[n++] = PackBwd16{w[8], 4, 256, 8, 1, PE16_NONE, 0, 1, CB16_HEAD, kexp + 8};
+    for (int l = 7; l >= 6; --l) d[n++] = PackBwd16{w[l], 256, 256, 8, 16, PE16_NONE, 0, 0, CB16_L7 + (7 - l) * CB16_FULL, kexp + l};
+    d[n++] = PackBwd16{w[5], 256, 319, 8, 16, PE16_NONE, 63, 0, CB16_L7 + 2 * CB16_FULL, kexp + 5};
+    d[n++] = PackBwd16{w[5], 256, 319, 2, 16, PE16_CANONICAL, 0, 0, CB16_L5P, kexp + 5};
+    for (int l = 4; l >= 1; --l) d[n++] = PackBwd16{w[l], 256, 256, 8, 16, PE16_NONE, 0, 0, CB16_L4 + (4 - l) * CB16_FULL, kexp + l};
+    d[n++] = PackBwd16{w[0], 256, 63, 2, 16, PE16_CANONICAL, 0, 0, CB16_L0P, kexp};
+    return launch_pack_bwd16(d, n, out, st);
 }
 
 // half != 0: dZ is an f16 matrix in the chain's scaled domain and dz_amax receives the [8] scales instead of maxima
@@ -1641,18 +1659,15 @@ int nonrigid16_bwd_pack(const float* const* w, void* packed, hipStream_t st) {
     const int sizes[7] = {128 * 105, 128 * 128, 128 * 128, 128 * 128, 128 * 164, 128 * 128, 3 * 128};
     int rc;
     if ((rc = launch_layer_amax(w, sizes, 7, kexp, st))) return rc;
-    auto launch = [&](const PackBwd16& d) {
-        const int64_t n = (int64_t)d.NT * 2 * d.NK * 256;
-        hipLaunchKernelGGL(pack_bwd16_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d, out);
-        return check_launch("hnrf pack (backward, f16x3)");
-    };
-    if ((rc = launch(PackBwd16{w[6], 3, 128, 4, 1, PE16_NONE, 0, 1, NB16_HEAD, kexp + 6}))) return rc;
-    if ((rc = launch(PackBwd16{w[5], 128, 128, 4, 8, PE16_NONE, 0, 0, NB16_L5, kexp + 5}))) return rc;
-    if ((rc = launch(PackBwd16{w[4], 128, 164, 4, 8, PE16_NONE, 0, 0, NB16_L5 + NB16_FULL, kexp + 4}))) return rc;
-    if ((rc = launch(PackBwd16{w[4], 128, 164, 2, 8, PE16_NONRIGID, 128, 0, NB16_L4P, kexp + 4}))) return rc;
-    for (int l = 3; l >= 1; --l)
-        if ((rc = launch(PackBwd16{w[l], 128, 128, 4, 8, PE16_NONE, 0, 0, NB16_L3 + (3 - l) * NB16_FULL, kexp + l}))) return rc;
-    return launch(PackBwd16{w[0], 128, 105, 2, 8, PE16_NONRIGID, 69, 0, NB16_L0P, kexp});
+    PackBwd16 d[10];
+    int n = 0;
+    d[n++] = PackBwd16{w[6], 3, 128, 4, 1, PE16_NONE, 0, 1, NB16_HEAD, kexp + 6};
+    d[n++] = PackBwd16{w[5], 128, 128, 4, 8, PE16_NONE, 0, 0, NB16_L5, kexp + 5};
+    d[n++] = PackBwd16{w[4], 128, 164, 4, 8, PE16_NONE, 0, 0, NB16_L5 + NB16_FULL, kexp + 4};
+    d[n++] = PackBwd16{w[4], 128, 164, 2, 8, PE16_NONRIGID, 128, 0, NB16_L4P, kexp + 4};
+    for (int l = 3; l >= 1; --l) d[n++] = PackBwd16{w[l], 128, 128, 4, 8, PE16_NONE, 0, 0, NB16_L3 + (3 - l) * NB16_FULL, kexp + l};
+    d[n++] = PackBwd16{w[0], 128, 105, 2, 8, PE16_NONRIGID, 69, 0, NB16_L0P, kexp};
+    return launch_pack_bwd16(d, n, out, st);
 }
 
 int nonrigid16_bwd(const float* x_skel, const float* hann_w, const float* d_xyz, const uint32_t* relu_bits,

@@ -11,6 +11,11 @@
 // rounded fp32 values of the exact formulas, i.e. at least as close to the reference as its own fp32 evaluation.
 // Backward: dInv_i = C_i^T gF_i,  dA_i = -A_i^-T dInv_i A_i^-T,  then down the tree in reverse bone order
 //   dG_i = A_p^T dA_i,  dA_p += dA_i G_i^T.
+//
+// With ``rvec`` the pose refinement in front of it is folded in as well (BodyPoseRefiner's Rodrigues step,
+// network_util.py:57-83, and network.py:677-688): R_i <- R_i Rodrigues(rvec_{i-1}) for the 23 non-root bones,
+//   theta = sqrt(1e-5 + |r|^2), n = r / theta, Rodrigues = (1 - cos) n n^T + cos I + sin [n]x,
+// ~150 more elementwise launches of a few hundred bytes each (forward + autograd) per training step otherwise.
 #include "hnrf_common.h"
 
 namespace hnrf {
@@ -73,9 +78,32 @@ __device__ inline void inv4(const double* a, double* inv) {
         for (int j = 0; j < 4; ++j) inv[4 * i + j] = m[i][4 + j];
 }
 
-__device__ inline void load_G(const float* Rs, const float* Ts, int i, double* g) {
+// Rodrigues(rvec) with the reference's regularised angle; n is NOT a unit vector (|n|^2 = |r|^2 / (1e-5 + |r|^2))
+__device__ inline void rodrigues3(const float* rvec, double* R, double* n, double* theta, double* cs) {
+    const double rx = (double)rvec[0], ry = (double)rvec[1], rz = (double)rvec[2];
+    const double th = sqrt(1e-5 + rx * rx + ry * ry + rz * rz);
+    const double x = rx / th, y = ry / th, z = rz / th, c = cos(th), sn = sin(th), oc = 1.0 - c;
+    R[0] = x * x + (1.0 - x * x) * c; R[1] = x * y * oc - z * sn;       R[2] = x * z * oc + y * sn;
+    R[3] = x * y * oc + z * sn;       R[4] = y * y + (1.0 - y * y) * c; R[5] = y * z * oc - x * sn;
+    R[6] = x * z * oc - y * sn;       R[7] = y * z * oc + x * sn;       R[8] = z * z + (1.0 - z * z) * c;
+    n[0] = x; n[1] = y; n[2] = z;
+    *theta = th;
+    cs[0] = c; cs[1] = sn;
+}
+
+// G_i = [R_i (Rodrigues(rvec_{i-1}) for i >= 1 when rvec is given) | T_i ; 0 0 0 1]
+__device__ inline void load_G(const float* Rs, const float* Ts, const float* rvec, int i, double* g) {
+    double R[9];
+    for (int k = 0; k < 9; ++k) R[k] = (double)Rs[9 * i + k];
+    if (rvec != nullptr && i >= 1) {
+        double D[9], n[3], th, cs[2], M[9];
+        rodrigues3(rvec + 3 * (i - 1), D, n, &th, cs);
+        for (int r = 0; r < 3; ++r)
+            for (int c = 0; c < 3; ++c) M[3 * r + c] = R[3 * r] * D[c] + R[3 * r + 1] * D[3 + c] + R[3 * r + 2] * D[6 + c];
+        for (int k = 0; k < 9; ++k) R[k] = M[k];
+    }
     for (int r = 0; r < 3; ++r) {
-        for (int c = 0; c < 3; ++c) g[4 * r + c] = (double)Rs[9 * i + 3 * r + c];
+        for (int c = 0; c < 3; ++c) g[4 * r + c] = R[3 * r + c];
         g[4 * r + 3] = (double)Ts[3 * i + r];
     }
     g[12] = g[13] = g[14] = 0.0;
@@ -83,20 +111,20 @@ __device__ inline void load_G(const float* Rs, const float* Ts, int i, double* g
 }
 
 // saved: [A (24 x 16) | A^-1 (24 x 16)] doubles for the backward
-__global__ __launch_bounds__(64) void motion_basis_fwd_kernel(const float* __restrict__ dst_Rs,
+__global__ __launch_bounds__(64) void motion_basis_fwd_kernel(const float* __restrict__ rvec,
+                                                              const float* __restrict__ dst_Rs,
                                                               const float* __restrict__ dst_Ts,
                                                               const float* __restrict__ cnl_gtfms,
                                                               float* __restrict__ Rs, float* __restrict__ Ts,
                                                               double* __restrict__ saved) {
+    __shared__ double G[POSE_B][16];
     __shared__ double A[POSE_B][16];
     const int i = threadIdx.x;
+    if (i < POSE_B) load_G(dst_Rs, dst_Ts, rvec, i, G[i]);
+    __syncthreads();
     if (i == 0) {
-        double g[16];
-        load_G(dst_Rs, dst_Ts, 0, A[0]);
-        for (int b = 1; b < POSE_B; ++b) {
-            load_G(dst_Rs, dst_Ts, b, g);
-            mm4(A[kSmplParent[b]], g, A[b]);
-        }
+        for (int k = 0; k < 16; ++k) A[0][k] = G[0][k];
+        for (int b = 1; b < POSE_B; ++b) mm4(A[kSmplParent[b]], G[b], A[b]);
     }
     __syncthreads();
     if (i < POSE_B) {
@@ -117,15 +145,20 @@ __global__ __launch_bounds__(64) void motion_basis_fwd_kernel(const float* __res
 }
 
 __global__ __launch_bounds__(64) void motion_basis_bwd_kernel(const float* __restrict__ g_Rs, const float* __restrict__ g_Ts,
+                                                              const float* __restrict__ rvec,
                                                               const float* __restrict__ dst_Rs,
                                                               const float* __restrict__ dst_Ts,
                                                               const float* __restrict__ cnl_gtfms,
                                                               const double* __restrict__ saved,
+                                                              float* __restrict__ d_rvec,
                                                               float* __restrict__ d_dst_Rs, float* __restrict__ d_dst_Ts) {
     __shared__ double dA[POSE_B][16];
+    __shared__ double G[POSE_B][16];
+    __shared__ double dG[POSE_B][16];
     const int i = threadIdx.x;
     if (i < POSE_B) {
         double gf[16], c[16], dinv[16], t[16];
+        load_G(dst_Rs, dst_Ts, rvec, i, G[i]);
         for (int r = 0; r < 3; ++r) {
             for (int cc = 0; cc < 3; ++cc) gf[4 * r + cc] = (double)g_Rs[9 * i + 3 * r + cc];
             gf[4 * r + 3] = (double)g_Ts[3 * i + r];
@@ -140,21 +173,53 @@ __global__ __launch_bounds__(64) void motion_basis_bwd_kernel(const float* __res
     }
     __syncthreads();
     if (i == 0) {
-        double g[16], dg[16], t[16];
+        double t[16];
         for (int b = POSE_B - 1; b >= 1; --b) {                  // children come after their parents
             const int p = kSmplParent[b];
-            load_G(dst_Rs, dst_Ts, b, g);
-            mm4_tn(saved + 16 * p, dA[b], dg);                   // dG_b = A_p^T dA_b
-            mm4_nt(dA[b], g, t);                                 // dA_p += dA_b G_b^T
+            mm4_tn(saved + 16 * p, dA[b], dG[b]);                // dG_b = A_p^T dA_b
+            mm4_nt(dA[b], G[b], t);                              // dA_p += dA_b G_b^T
             for (int k = 0; k < 16; ++k) dA[p][k] += t[k];
-            for (int r = 0; r < 3; ++r) {
-                for (int cc = 0; cc < 3; ++cc) d_dst_Rs[9 * b + 3 * r + cc] = (float)dg[4 * r + cc];
-                d_dst_Ts[3 * b + r] = (float)dg[4 * r + 3];
-            }
         }
-        for (int r = 0; r < 3; ++r) {                            // A_0 = G_0
-            for (int cc = 0; cc < 3; ++cc) d_dst_Rs[3 * r + cc] = (float)dA[0][4 * r + cc];
-            d_dst_Ts[r] = (float)dA[0][4 * r + 3];
+        for (int k = 0; k < 16; ++k) dG[0][k] = dA[0][k];        // A_0 = G_0
+    }
+    __syncthreads();
+    if (i < POSE_B) {
+        double gR[9];                                            // gradient at the (refined) rotation of G_i
+        for (int r = 0; r < 3; ++r) {
+            for (int cc = 0; cc < 3; ++cc) gR[3 * r + cc] = dG[i][4 * r + cc];
+            d_dst_Ts[3 * i + r] = (float)dG[i][4 * r + 3];
+        }
+        if (rvec == nullptr || i == 0) {
+            for (int k = 0; k < 9; ++k) d_dst_Rs[9 * i + k] = (float)gR[k];
+        } else {
+            double D[9], n[3], th, cs[2], R0[9], gD[9];
+            rodrigues3(rvec + 3 * (i - 1), D, n, &th, cs);
+            for (int k = 0; k < 9; ++k) R0[k] = (double)dst_Rs[9 * i + k];
+            for (int r = 0; r < 3; ++r)
+                for (int cc = 0; cc < 3; ++cc) {
+                    // R = R0 D:  dR0 = gR D^T,  dD = R0^T gR
+                    d_dst_Rs[9 * i + 3 * r + cc] =
+                        (float)(gR[3 * r] * D[3 * cc] + gR[3 * r + 1] * D[3 * cc + 1] + gR[3 * r + 2] * D[3 * cc + 2]);
+                    gD[3 * r + cc] = R0[r] * gR[cc] + R0[3 + r] * gR[3 + cc] + R0[6 + r] * gR[6 + cc];
+                }
+            // D = (1 - c) n n^T + c I + s [n]x
+            const double c = cs[0], sn = cs[1], oc = 1.0 - c, x = n[0], y = n[1], z = n[2];
+            double gn_[3], gtn[3];                               // gD n, gD^T n
+            for (int r = 0; r < 3; ++r) {
+                gn_[r] = gD[3 * r] * x + gD[3 * r + 1] * y + gD[3 * r + 2] * z;
+                gtn[r] = gD[r] * x + gD[3 + r] * y + gD[6 + r] * z;
+            }
+            const double g_c = gD[0] + gD[4] + gD[8] - (x * gn_[0] + y * gn_[1] + z * gn_[2]);
+            const double ax = gD[7] - gD[5], ay = gD[2] - gD[6], az = gD[3] - gD[1];   // axial part of gD
+            const double g_s = x * ax + y * ay + z * az;
+            const double g_n[3] = {oc * (gn_[0] + gtn[0]) + sn * ax, oc * (gn_[1] + gtn[1]) + sn * ay,
+                                   oc * (gn_[2] + gtn[2]) + sn * az};
+            const double g_th = -sn * g_c + c * g_s;
+            const double rx = x * th, ry = y * th, rz = z * th;
+            const double k = (g_th - (g_n[0] * rx + g_n[1] * ry + g_n[2] * rz) / (th * th)) / th;
+            d_rvec[3 * (i - 1) + 0] = (float)(g_n[0] / th + k * rx);
+            d_rvec[3 * (i - 1) + 1] = (float)(g_n[1] / th + k * ry);
+            d_rvec[3 * (i - 1) + 2] = (float)(g_n[2] / th + k * rz);
         }
     }
 }
@@ -170,8 +235,8 @@ extern "C" int hnrf_motion_basis_fwd(const float* dst_Rs, const float* dst_Ts, c
     HNRF_REQUIRE(dst_Rs && dst_Ts && cnl_gtfms && Rs && Ts, HNRF_E_ARG, "hnrf_motion_basis_fwd: null pointer");
     HNRF_REQUIRE(B == POSE_B, HNRF_E_UNSUPPORTED, "hnrf_motion_basis_fwd: %d bones (the SMPL tree has 24)", B);
     HNRF_REQUIRE(((uintptr_t)saved & 7) == 0, HNRF_E_ARG, "hnrf_motion_basis_fwd: saved must be 8-byte aligned");
-    hipLaunchKernelGGL(motion_basis_fwd_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, dst_Rs, dst_Ts, cnl_gtfms, Rs, Ts,
-                       (double*)saved);
+    hipLaunchKernelGGL(motion_basis_fwd_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (const float*)nullptr, dst_Rs,
+                       dst_Ts, cnl_gtfms, Rs, Ts, (double*)saved);
     return check_launch("hnrf_motion_basis_fwd");
 }
 
@@ -181,7 +246,28 @@ extern "C" int hnrf_motion_basis_bwd(const float* g_Rs, const float* g_Ts, const
     HNRF_REQUIRE(g_Rs && g_Ts && dst_Rs && dst_Ts && cnl_gtfms && saved && d_dst_Rs && d_dst_Ts, HNRF_E_ARG,
                  "hnrf_motion_basis_bwd: null pointer");
     HNRF_REQUIRE(B == POSE_B, HNRF_E_UNSUPPORTED, "hnrf_motion_basis_bwd: %d bones (the SMPL tree has 24)", B);
-    hipLaunchKernelGGL(motion_basis_bwd_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, g_Rs, g_Ts, dst_Rs, dst_Ts,
-                       cnl_gtfms, (const double*)saved, d_dst_Rs, d_dst_Ts);
+    hipLaunchKernelGGL(motion_basis_bwd_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, g_Rs, g_Ts, (const float*)nullptr,
+                       dst_Rs, dst_Ts, cnl_gtfms, (const double*)saved, (float*)nullptr, d_dst_Rs, d_dst_Ts);
     return check_launch("hnrf_motion_basis_bwd");
+}
+
+extern "C" int hnrf_refined_motion_basis_fwd(const float* rvec, const float* dst_Rs, const float* dst_Ts,
+                                             const float* cnl_gtfms, int B, float* Rs, float* Ts, void* saved, void* stream) {
+    HNRF_REQUIRE(rvec && dst_Rs && dst_Ts && cnl_gtfms && Rs && Ts, HNRF_E_ARG, "hnrf_refined_motion_basis_fwd: null pointer");
+    HNRF_REQUIRE(B == POSE_B, HNRF_E_UNSUPPORTED, "hnrf_refined_motion_basis_fwd: %d bones (the SMPL tree has 24)", B);
+    HNRF_REQUIRE(((uintptr_t)saved & 7) == 0, HNRF_E_ARG, "hnrf_refined_motion_basis_fwd: saved must be 8-byte aligned");
+    hipLaunchKernelGGL(motion_basis_fwd_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, rvec, dst_Rs, dst_Ts, cnl_gtfms, Rs,
+                       Ts, (double*)saved);
+    return check_launch("hnrf_refined_motion_basis_fwd");
+}
+
+extern "C" int hnrf_refined_motion_basis_bwd(const float* g_Rs, const float* g_Ts, const float* rvec, const float* dst_Rs,
+                                             const float* dst_Ts, const float* cnl_gtfms, int B, const void* saved,
+                                             float* d_rvec, float* d_dst_Rs, float* d_dst_Ts, void* stream) {
+    HNRF_REQUIRE(g_Rs && g_Ts && rvec && dst_Rs && dst_Ts && cnl_gtfms && saved && d_rvec && d_dst_Rs && d_dst_Ts, HNRF_E_ARG,
+                 "hnrf_refined_motion_basis_bwd: null pointer");
+    HNRF_REQUIRE(B == POSE_B, HNRF_E_UNSUPPORTED, "hnrf_refined_motion_basis_bwd: %d bones (the SMPL tree has 24)", B);
+    hipLaunchKernelGGL(motion_basis_bwd_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, g_Rs, g_Ts, rvec, dst_Rs, dst_Ts,
+                       cnl_gtfms, (const double*)saved, d_rvec, d_dst_Rs, d_dst_Ts);
+    return check_launch("hnrf_refined_motion_basis_bwd");
 }

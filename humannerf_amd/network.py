@@ -221,8 +221,12 @@ class BodyPoseRefiner(nn.Module):
         _init_sequence(self.block_mlps)
         _tiny_last_layer(self.block_mlps[-1])
 
+    def rvec(self, pose_input):
+        """The MLP alone: axis-angle corrections (N * 23, 3)."""
+        return self.block_mlps(pose_input).view(-1, 3)
+
     def forward(self, pose_input):
-        rvec = self.block_mlps(pose_input).view(-1, 3)
+        rvec = self.rvec(pose_input)
         return {'Rs': rodrigues(rvec).view(-1, self.total_bones, 3, 3),
                 'rvec': rvec.view(-1, self.total_bones, 3)}
 
@@ -244,26 +248,32 @@ class _MotionBasis(torch.autograd.Function):
     (hnrf_motion_basis_fwd / _bwd) instead of ~120 tiny PyTorch launches per training step."""
 
     @staticmethod
-    def forward(ctx, dst_Rs, dst_Ts, cnl_gtfms):
+    def forward(ctx, dst_Rs, dst_Ts, cnl_gtfms, rvec=None):
         dst_Rs, dst_Ts, cnl_gtfms = dst_Rs.contiguous(), dst_Ts.contiguous(), cnl_gtfms.contiguous()
-        need = dst_Rs.requires_grad or dst_Ts.requires_grad
-        Rs, Ts, saved = ops.motion_basis_fwd(dst_Rs, dst_Ts, cnl_gtfms, want_saved=need)
+        rvec = rvec.contiguous() if rvec is not None else None
+        need = dst_Rs.requires_grad or dst_Ts.requires_grad or (rvec is not None and rvec.requires_grad)
+        Rs, Ts, saved = ops.motion_basis_fwd(dst_Rs, dst_Ts, cnl_gtfms, want_saved=need, rvec=rvec)
+        ctx.refined = rvec is not None
         if need:
-            ctx.save_for_backward(dst_Rs, dst_Ts, cnl_gtfms, saved)
+            ctx.save_for_backward(dst_Rs, dst_Ts, cnl_gtfms, saved, *((rvec,) if ctx.refined else ()))
         return Rs, Ts
 
     @staticmethod
     def backward(ctx, g_Rs, g_Ts):
-        dst_Rs, dst_Ts, cnl_gtfms, saved = ctx.saved_tensors
-        d_Rs, d_Ts = ops.motion_basis_bwd(g_Rs.contiguous(), g_Ts.contiguous(), dst_Rs, dst_Ts, cnl_gtfms, saved)
-        return d_Rs, d_Ts, None
+        dst_Rs, dst_Ts, cnl_gtfms, saved = ctx.saved_tensors[:4]
+        rvec = ctx.saved_tensors[4] if ctx.refined else None
+        out = ops.motion_basis_bwd(g_Rs.contiguous(), g_Ts.contiguous(), dst_Rs, dst_Ts, cnl_gtfms, saved, rvec=rvec)
+        return out[0], out[1], None, (out[2] if ctx.refined else None)
 
 
-def motion_basis(dst_Rs, dst_Ts, cnl_gtfms):
-    """MotionBasisComputer.forward for one frame: (B,3,3),(B,3),(B,4,4) -> (B,3,3),(B,3).  On the GPU: the fused kernel;
-    the torch restatement below it serves CPU-side checks only."""
+def motion_basis(dst_Rs, dst_Ts, cnl_gtfms, rvec=None):
+    """MotionBasisComputer.forward for one frame: (B,3,3),(B,3),(B,4,4) -> (B,3,3),(B,3).  ``rvec`` (B-1,3): the pose
+    refinement dst_Rs[1:] <- dst_Rs[1:] Rodrigues(rvec) (network.py:677-688) applied first.  On the GPU: the fused
+    kernel; the torch restatement below it serves CPU-side checks only."""
     if dst_Rs.is_cuda and dst_Rs.shape[0] == 24:
-        return _MotionBasis.apply(dst_Rs, dst_Ts, cnl_gtfms)
+        return _MotionBasis.apply(dst_Rs, dst_Ts, cnl_gtfms, rvec)
+    if rvec is not None:
+        dst_Rs = torch.cat([dst_Rs[0:1], torch.matmul(dst_Rs[1:], rodrigues(rvec))], dim=0)
     return motion_basis_torch(dst_Rs, dst_Ts, cnl_gtfms)
 
 
@@ -434,16 +444,16 @@ class Network(nn.Module):
         cnl_gtfms, priors = f32(cnl_gtfms), f32(motion_weights_priors)
 
         # pose refinement (network.py:667-688)
+        rvec = None
         if iter_val >= cfg.pose_decoder.get('kick_in_iter', 0) and not cfg.get('pose_decoder_off', False):
-            dR = self.pose_decoder(dst_posevec[None])['Rs'][0]            # (23,3,3)
-            dst_Rs = torch.cat([dst_Rs[0:1], torch.matmul(dst_Rs[1:], dR)], dim=0)
+            rvec = self.pose_decoder.rvec(dst_posevec[None])              # (23,3); Rodrigues + correction: motion_basis
 
         ignore_nr = bool(cfg.ignore_non_rigid_motions)
         nr_cfg = cfg.non_rigid_motion_mlp
         cond = dst_posevec
         if iter_val < nr_cfg.kick_in_iter:
             cond = torch.zeros_like(cond) * cond                            # network.py:735-737
-        motion_Rs, motion_Ts = motion_basis(dst_Rs, dst_Ts, cnl_gtfms)
+        motion_Rs, motion_Ts = motion_basis(dst_Rs, dst_Ts, cnl_gtfms, rvec)
         vol = self._weight_volume(priors)
         self.motion_weights_vol = vol
         if train_path and self.grad_sync is not None:

@@ -473,26 +473,41 @@ def mlp_dw_h(dZ, X, dW_out=None, want_db=True, dz_scale=None, n_in=None, P=None,
     return dW_out, db
 
 
-def motion_basis_fwd(dst_Rs, dst_Ts, cnl_gtfms, want_saved=False):
-    """hnrf_motion_basis_fwd: (B,3,3), (B,3), (B,4,4) -> Rs (B,3,3), Ts (B,3) [, saved state for the backward]."""
+def motion_basis_fwd(dst_Rs, dst_Ts, cnl_gtfms, want_saved=False, rvec=None):
+    """hnrf_motion_basis_fwd: (B,3,3), (B,3), (B,4,4) -> Rs (B,3,3), Ts (B,3) [, saved state for the backward].
+    With ``rvec`` (B-1,3): hnrf_refined_motion_basis_fwd (the pose refinement's Rodrigues correction folded in)."""
     lib = _lib.load()
     _chk(dst_Rs, dst_Ts, cnl_gtfms)
     B = dst_Rs.shape[0]
     assert dst_Rs.shape == (B, 3, 3) and dst_Ts.shape == (B, 3) and cnl_gtfms.shape == (B, 4, 4)
     Rs, Ts = torch.empty_like(dst_Rs), torch.empty_like(dst_Ts)
     saved = torch.empty(lib.hnrf_motion_basis_saved_bytes() // 8, dtype=torch.float64, device=dst_Rs.device) if want_saved else None
-    _lib.check(lib.hnrf_motion_basis_fwd(_ptr(dst_Rs), _ptr(dst_Ts), _ptr(cnl_gtfms), B, _ptr(Rs), _ptr(Ts), _ptr(saved),
-                                         _stream()), 'hnrf_motion_basis_fwd')
+    if rvec is None:
+        _lib.check(lib.hnrf_motion_basis_fwd(_ptr(dst_Rs), _ptr(dst_Ts), _ptr(cnl_gtfms), B, _ptr(Rs), _ptr(Ts), _ptr(saved),
+                                             _stream()), 'hnrf_motion_basis_fwd')
+    else:
+        _chk(rvec)
+        assert rvec.shape == (B - 1, 3)
+        _lib.check(lib.hnrf_refined_motion_basis_fwd(_ptr(rvec), _ptr(dst_Rs), _ptr(dst_Ts), _ptr(cnl_gtfms), B, _ptr(Rs),
+                                                     _ptr(Ts), _ptr(saved), _stream()), 'hnrf_refined_motion_basis_fwd')
     return Rs, Ts, saved
 
 
-def motion_basis_bwd(g_Rs, g_Ts, dst_Rs, dst_Ts, cnl_gtfms, saved):
+def motion_basis_bwd(g_Rs, g_Ts, dst_Rs, dst_Ts, cnl_gtfms, saved, rvec=None):
+    """-> d_dst_Rs, d_dst_Ts [, d_rvec when ``rvec`` is given]."""
     lib = _lib.load()
     _chk(g_Rs, g_Ts, dst_Rs, dst_Ts, cnl_gtfms)
     d_Rs, d_Ts = torch.empty_like(dst_Rs), torch.empty_like(dst_Ts)
-    _lib.check(lib.hnrf_motion_basis_bwd(_ptr(g_Rs), _ptr(g_Ts), _ptr(dst_Rs), _ptr(dst_Ts), _ptr(cnl_gtfms), dst_Rs.shape[0],
-                                         _ptr(saved), _ptr(d_Rs), _ptr(d_Ts), _stream()), 'hnrf_motion_basis_bwd')
-    return d_Rs, d_Ts
+    if rvec is None:
+        _lib.check(lib.hnrf_motion_basis_bwd(_ptr(g_Rs), _ptr(g_Ts), _ptr(dst_Rs), _ptr(dst_Ts), _ptr(cnl_gtfms), dst_Rs.shape[0],
+                                             _ptr(saved), _ptr(d_Rs), _ptr(d_Ts), _stream()), 'hnrf_motion_basis_bwd')
+        return d_Rs, d_Ts
+    _chk(rvec)
+    d_rvec = torch.empty_like(rvec)
+    _lib.check(lib.hnrf_refined_motion_basis_bwd(_ptr(g_Rs), _ptr(g_Ts), _ptr(rvec), _ptr(dst_Rs), _ptr(dst_Ts), _ptr(cnl_gtfms),
+                                                 dst_Rs.shape[0], _ptr(saved), _ptr(d_rvec), _ptr(d_Rs), _ptr(d_Ts), _stream()),
+               'hnrf_refined_motion_basis_bwd')
+    return d_Rs, d_Ts, d_rvec
 
 
 def sample_warp_bwd(rays_o, rays_d, z_vals, motion_Rs, motion_Ts, vol, bbox_min, bbox_scale, x_skel, fg_mask,

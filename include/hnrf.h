@@ -242,6 +242,15 @@ int hnrf_motion_basis_fwd(const float* dst_Rs, const float* dst_Ts, const float*
                           void* saved, void* stream);
 int hnrf_motion_basis_bwd(const float* g_Rs, const float* g_Ts, const float* dst_Rs, const float* dst_Ts,
                           const float* cnl_gtfms, int B, const void* saved, float* d_dst_Rs, float* d_dst_Ts, void* stream);
+/* The same with the pose refinement in front folded in (BodyPoseRefiner's Rodrigues step, core/utils/network_util.py:57-83,
+ * and the correction of core/nets/human_nerf/network.py:677-688): dst_Rs[i] <- dst_Rs[i] Rodrigues(rvec[i-1]) for the 23
+ * non-root bones, theta = sqrt(1e-5 + |r|^2).  rvec [23,3] = the pose MLP's output.  bwd also returns d_rvec [23,3]
+ * (d_dst_Rs is the gradient at the UNrefined rotations). */
+int hnrf_refined_motion_basis_fwd(const float* rvec, const float* dst_Rs, const float* dst_Ts, const float* cnl_gtfms, int B,
+                                  float* Rs, float* Ts, void* saved, void* stream);
+int hnrf_refined_motion_basis_bwd(const float* g_Rs, const float* g_Ts, const float* rvec, const float* dst_Rs,
+                                  const float* dst_Ts, const float* cnl_gtfms, int B, const void* saved, float* d_rvec,
+                                  float* d_dst_Rs, float* d_dst_Ts, void* stream);
 
 /* Weight / bias gradient of one nn.Linear inside the two MLPs (autograd of the Linear layers of
  * canonical_mlps/mlp_rgb_sigma.py and non_rigid_motion_mlps/mlp_offset.py under trainer.py:139-170):

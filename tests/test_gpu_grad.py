@@ -579,3 +579,37 @@ def test_motion_basis_kernels_match_fp64_autograd():
         # and the torch restatement it replaces agrees too (fp32)
         R2, T2 = motion_basis_torch(T(dst_Rs), T(dst_Ts), T(gt))
         assert float((R2 - Rs.detach()).abs().max()) <= 5e-6 and float((T2 - Ts.detach()).abs().max()) <= 5e-6
+
+
+def test_refined_motion_basis_kernels_match_fp64_autograd():
+    """hnrf_refined_motion_basis_fwd / _bwd: the pose refinement's Rodrigues correction (network_util.py:57-83,
+    network.py:677-688) folded into the kinematics kernels, vs torch fp64 autograd through the oracle's rodrigues +
+    motion_basis; rvec magnitudes from the freshly initialised refiner's 1e-5 up to large corrections."""
+    from humannerf_amd import scene
+    from humannerf_amd.network import motion_basis
+    from oracle import oracle
+    for seed, mag in ((0, 1e-5), (1, 1e-2), (2, 0.3), (3, 2.0)):
+        rs = np.random.RandomState(seed)
+        dst_Rs, dst_Ts = scene.body_pose_to_body_RTs(rs.randn(72) * 0.4, scene.TPOSE_JOINTS)
+        gt = scene.get_canonical_global_tfms(scene.TPOSE_JOINTS)
+        rv = (rs.randn(23, 3) * mag).astype(np.float32)
+        rv[5] = 0.0                                                    # exactly zero correction: theta = sqrt(1e-5)
+        T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev())
+        R_in, T_in, v_in = T(dst_Rs).requires_grad_(True), T(dst_Ts).requires_grad_(True), T(rv).requires_grad_(True)
+        Rs, Ts = motion_basis(R_in, T_in, T(gt), v_in)
+        gR, gT = rs.randn(24, 3, 3).astype(np.float32), rs.randn(24, 3).astype(np.float32)
+        ((Rs * T(gR)).sum() + (Ts * T(gT)).sum()).backward()
+        R64 = torch.from_numpy(dst_Rs).double().requires_grad_(True)
+        T64 = torch.from_numpy(dst_Ts).double().requires_grad_(True)
+        v64 = torch.from_numpy(rv).double().requires_grad_(True)
+        Rc = torch.cat([R64[0:1], torch.matmul(R64[1:], oracle.rodrigues(v64))], dim=0)
+        Rr, Tr = oracle.motion_basis(Rc, T64, torch.from_numpy(gt).double())
+        ((Rr * torch.from_numpy(gR).double()).sum() + (Tr * torch.from_numpy(gT).double()).sum()).backward()
+        assert float((Rs.detach().double().cpu() - Rr.detach()).abs().max()) <= 2e-7
+        assert float((Ts.detach().double().cpu() - Tr.detach()).abs().max()) <= 2e-7 * max(1.0, float(Tr.abs().max()))
+        for got, ref in ((R_in.grad, R64.grad), (T_in.grad, T64.grad), (v_in.grad, v64.grad)):
+            assert float((got.double().cpu() - ref).abs().max()) <= 2e-6 * float(ref.abs().max())
+        # without gradient (rendering) the same numbers come out
+        with torch.no_grad():
+            R3, T3 = motion_basis(T(dst_Rs), T(dst_Ts), T(gt), T(rv))
+        assert torch.equal(R3, Rs.detach()) and torch.equal(T3, Ts.detach())
