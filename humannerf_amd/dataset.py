@@ -85,6 +85,31 @@ def rodrigues_cv(rvec):
     return np.cos(theta) * np.eye(3) + (1.0 - np.cos(theta)) * np.outer(r, r) + np.sin(theta) * K
 
 
+def rotation_to_rvec(R):
+    """What cv2.Rodrigues(R)[0][:, 0] computes for a rotation matrix: the axis-angle vector with angle in [0, pi]."""
+    R = np.asarray(R, dtype=np.float64)
+    ax = np.array([R[2, 1] - R[1, 2], R[0, 2] - R[2, 0], R[1, 0] - R[0, 1]])
+    s, c = 0.5 * np.linalg.norm(ax), np.clip(0.5 * (np.trace(R) - 1.0), -1.0, 1.0)
+    theta = np.arctan2(s, c)
+    if s > 1e-9:
+        return ax / (2.0 * s) * theta
+    if c > 0:
+        return np.zeros(3)
+    # angle pi: axis from the diagonal of (R + I) / 2 = r r^T, signs from its largest column
+    B = 0.5 * (R + np.eye(3))
+    k = int(np.argmax(np.diag(B)))
+    r = B[:, k] / np.sqrt(B[k, k])
+    return r * theta
+
+
+def rotate_bbox(bbox, rmtx):
+    """tpose.py:102-124: axis-aligned box of the eight corners multiplied by ``rmtx`` from the right."""
+    mn, mx = np.asarray(bbox['min_xyz']), np.asarray(bbox['max_xyz'])
+    pts = np.array([[x, y, z] for x in (mn[0], mx[0]) for y in (mn[1], mx[1]) for z in (mn[2], mx[2])])
+    rot = pts.dot(rmtx)
+    return {'min_xyz': np.min(rot, axis=0), 'max_xyz': np.max(rot, axis=0)}
+
+
 def apply_global_tfm_to_camera(E, Rh, Th):
     """Extrinsics in the frame of the body's root (camera_util.py:117-131)."""
     g = np.eye(4)
@@ -230,6 +255,25 @@ class Subject:
         H, W = image_size
         out = {'frame_name': name, 'bgcolor': np.array([255., 255., 255.] if bgcolor is None else bgcolor, dtype='float32')}
         out.update(self._camera_entries(K, E, info, H, W, host_rays))
+        out.update(self._skeleton_entries(info))
+        return out
+
+    TPOSE_RENDER_SIZE = 512                                   # tpose.py:22-25
+    TPOSE_CAM_PARAMS = {'radius': 6.0, 'focal': 1250.}
+
+    def tpose_frame(self, idx, total_frames, bgcolor=None, host_rays=False, image_size=None):
+        """tpose.py:127-228 (run.py's 'tpose' mode): the canonical skeleton with zero pose, turned about the vertical
+        axis by 2 pi idx / total_frames through its root rotation, seen from the fixed camera of tpose.py:65-84."""
+        size = int(image_size or self.TPOSE_RENDER_SIZE)
+        angle = 2 * np.pi / total_frames * idx
+        add_rmtx = rodrigues_cv(np.array([0, -angle, 0], dtype='float32'))
+        poses = np.zeros(72, dtype='float32')
+        poses[:3] = rotation_to_rvec(add_rmtx.dot(rodrigues_cv(poses[:3])))
+        info = {'poses': poses, 'tpose_joints': self.canonical_joints,
+                'bbox': rotate_bbox(self.canonical_bbox, add_rmtx)}
+        K, E = scene.tpose_camera(size, **self.TPOSE_CAM_PARAMS)
+        out = {'bgcolor': np.array([255., 255., 255.] if bgcolor is None else bgcolor, dtype='float32')}
+        out.update(self._camera_entries(K, E, info, size, size, host_rays))
         out.update(self._skeleton_entries(info))
         return out
 

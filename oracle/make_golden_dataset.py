@@ -84,6 +84,37 @@ def main():
         expected[name + '/near'], expected[name + '/far'] = near[:, None].astype('float32'), far[:, None].astype('float32')
         expected[name + '/ray_mask'] = mask
         print(name, 'rays', int(mask.sum()), 'of', H * W)
+    # run.py's 'tpose' mode (core/data/human_nerf/tpose.py:127-228) through the reference's helpers, 64x64 image;
+    # the two cv2.Rodrigues conversions of the root rotation come from dataset.py (cv2 absent)
+    total = 8
+    for idx in (0, 3, 5):
+        angle = 2 * np.pi / total * idx
+        add = dataset.rodrigues_cv(np.array([0, -angle, 0], dtype='float32'))
+        poses = np.zeros(72, dtype='float32')
+        poses[:3] = dataset.rotation_to_rvec(add)
+        x, y, z = 0., -0.25, 6.0
+        campos = np.array([x, y, z], dtype='float32')
+        camrot = rc.get_camrot(campos, lookat=np.array([0, y, 0.]), inv_camera=True)
+        Et = np.eye(4, dtype='float32')
+        Et[:3, :3] = camrot
+        Et[:3, 3] = -camrot.dot(campos)
+        Kt = np.eye(3, dtype='float32')
+        Kt[0, 0] = Kt[1, 1] = 100.                                # (1250 in tpose.py: at 64 px every ray would hit)
+        Kt[:2, 2] = 64 / 2.
+        mnx, mxx = cmn, cmx
+        pts = np.array([[mnx[0], mnx[1], mnx[2]], [mnx[0], mnx[1], mxx[2]], [mnx[0], mxx[1], mnx[2]], [mnx[0], mxx[1], mxx[2]],
+                        [mxx[0], mnx[1], mnx[2]], [mxx[0], mnx[1], mxx[2]], [mxx[0], mxx[1], mnx[2]], [mxx[0], mxx[1], mxx[2]]]).dot(add)
+        bbox = {'min_xyz': pts.min(0), 'max_xyz': pts.max(0)}
+        ro, rd = rc.get_rays_from_KRT(64, 64, Kt, Et[:3, :3], Et[:3, 3])
+        ro, rd = ro.reshape(-1, 3), rd.reshape(-1, 3)
+        near, far, mask = rc.rays_intersect_3d_bbox(bbox, ro, rd)
+        Rs, Ts = rb.body_pose_to_body_RTs(poses, cj)
+        key = 'tpose%d/' % idx
+        expected[key + 'dst_Rs'], expected[key + 'dst_Ts'] = Rs, Ts
+        expected[key + 'rays'] = np.stack([ro[mask], rd[mask], rd[mask]], 0).astype('float32')
+        expected[key + 'near'], expected[key + 'far'] = near[:, None].astype('float32'), far[:, None].astype('float32')
+        expected[key + 'ray_mask'] = mask
+        print('tpose', idx, 'rays', int(mask.sum()))
     np.savez_compressed(os.path.join(REPO, 'tests', 'golden', 'subject_synth_expected.npz'), **expected)
     # the loader must refuse anything that is not plain data
     evil = os.path.join(OUT, 'not_data.pkl')

@@ -89,6 +89,34 @@ def test_freeview_frame_orbits(subj):
     assert tuple(f0['bgcolor']) == (255., 255., 255.)                       # freeview.py:74
 
 
+@pytest.mark.parametrize('idx', [0, 3, 5])
+def test_tpose_frame_matches_reference_helpers(subj, want, idx):
+    """run.py's 'tpose' mode (tpose.py:127-228): zero pose turned about the vertical axis, fixed camera; rays / near /
+    far / mask and the bone transforms against the reference's numpy helpers (fixture: oracle/make_golden_dataset.py)."""
+    subj.TPOSE_CAM_PARAMS = {'radius': 6.0, 'focal': 100.}
+    fr = subj.tpose_frame(idx, 8, host_rays=True, image_size=64)
+    key = 'tpose%d/' % idx
+    assert np.array_equal(fr['ray_mask'], want[key + 'ray_mask']) and 0 < fr['ray_mask'].sum() < 64 * 64
+    for k in ('rays', 'near', 'far', 'dst_Rs', 'dst_Ts'):
+        assert fr[k].shape == want[key + k].shape
+        assert np.abs(fr[k] - want[key + k]).max() <= 2e-6, k
+    assert np.allclose(fr['dst_posevec'], 0.01) and fr['bgcolor'].tolist() == [255., 255., 255.]
+    assert np.array_equal(fr['cnl_bbox_min_xyz'], want['cnl_bbox_min_xyz'])
+    # camera-only form for the device ray generator carries the rotated box
+    cam = subj.tpose_frame(idx, 8, image_size=64)
+    assert 'rays' not in cam and cam['K'][0, 0] == 100. and cam['ray_bbox_min_xyz'].shape == (3,)
+
+
+def test_rotation_to_rvec_inverts_rodrigues():
+    from humannerf_amd import dataset
+    rs = np.random.RandomState(5)
+    for v in [rs.randn(3) * s for s in (1e-6, 0.1, 1.0, 2.0)] + [np.array([0, np.pi, 0.]), np.array([0, -2.5, 0.]), np.zeros(3)]:
+        R = dataset.rodrigues_cv(v)
+        back = dataset.rotation_to_rvec(R)
+        assert np.linalg.norm(back) <= np.pi + 1e-9
+        assert np.abs(dataset.rodrigues_cv(back) - R).max() <= 1e-9
+
+
 def test_rodrigues_and_global_transform():
     """cv2 is absent: closed-form properties only (parity with OpenCV's numerics unpinned)."""
     rs = np.random.RandomState(3)
