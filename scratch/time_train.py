@@ -11,6 +11,7 @@ from humannerf_amd.seeded import default_shapes, seeded_state
 dev = torch.device('cuda:0')
 cfg.amd.train_operands = sys.argv[1] if len(sys.argv) > 1 else 'f16'
 iters = int(sys.argv[2]) if len(sys.argv) > 2 else 4
+cfg.amd.train_check_every = int(os.environ.get('HNRF_CHECK_EVERY', 200))
 state = seeded_state(default_shapes(), 0)
 net = Network(); net.load_state_dict({k: torch.from_numpy(v) for k, v in state.items()}); net = net.to(dev).train()
 fr = scene.synthetic_frame(H=512, W=512, focal_at_512=1700.0)
