@@ -155,6 +155,9 @@ _DEFAULTS = {
         # decoder's 254 MB of gradients never travel; needs the same priors on every rank, verified at run time),
         # 'full' = plain all-reduce of every gradient
         'ddp_reduce': 'volume',
+        # run the collectives of the training step even when world_size == 1 (identities over a one-rank group):
+        # exercises the RCCL code path on a single-GPU box (tests/test_gpu_dist.py)
+        'ddp_single_rank_collectives': False,
     },
 }
 

@@ -74,9 +74,12 @@ class GradientSync:
     parameter rides in the same bucket and is checked (one step late) to be 0 or ``world`` everywhere.
     """
 
-    def __init__(self, network, world, group=None, mode='volume', resync_every=1000):
+    def __init__(self, network, world, group=None, mode='volume', resync_every=1000, single_rank_collectives=False):
         assert mode in ('volume', 'full')
         self.world, self.group, self.mode = int(world), group, mode
+        # world == 1 needs no collective; with ``single_rank_collectives`` they run anyway (over a 1-rank group they are
+        # identities): the way to exercise the RCCL code path itself on a box with one GPU (tests/test_gpu_dist.py)
+        self.active = self.world > 1 or bool(single_rank_collectives)
         # volume mode: every rank computes the decoder gradients itself from the same averaged volume gradient.  They
         # agree bit for bit as long as the library GEMMs of the decoder backward are run-to-run deterministic; as
         # insurance against replicas drifting apart over 400 k iterations the decoder parameters are re-broadcast from
@@ -93,7 +96,7 @@ class GradientSync:
     # -- backward-time hook -------------------------------------------------------------------------------
     def volume_hook(self, vol, priors=None):
         """Wrap the decoded weight volume: its gradient is averaged over the ranks on its way into the decoder."""
-        if self.world == 1 or self.mode != 'volume' or not vol.requires_grad:
+        if not self.active or self.mode != 'volume' or not vol.requires_grad:
             return vol
         if priors is not None:
             self._check_same(priors.double().sum().reshape(1), 'motion_weights_priors differ between ranks: the '
@@ -105,7 +108,7 @@ class GradientSync:
     def reduce(self):
         """Mean-all-reduce the gradients outside the volume hook; in place, None gradients stay None."""
         self._poll()
-        if self.world == 1:
+        if not self.active:
             return
         self.steps += 1
         if self.mode == 'volume' and self.resync_every > 0 and self.steps % self.resync_every == 0:

@@ -138,8 +138,9 @@ class Trainer:
         self.world_size = int(world_size)
         self.logdir = logdir if logdir is not None else cfg.get('logdir', None)
         self.grad_sync = hdist.GradientSync(network, self.world_size, group=process_group,
-                                            mode=amd_option('ddp_reduce', 'volume'))
-        network.grad_sync = self.grad_sync if self.world_size > 1 else None
+                                            mode=amd_option('ddp_reduce', 'volume'),
+                                            single_rank_collectives=amd_option('ddp_single_rank_collectives', False))
+        network.grad_sync = self.grad_sync if self.grad_sync.active else None
         weights = {k: v for k, v in cfg.train.lossweights.items() if v > 0}
         self.objective = ' + '.join('%g*%s' % (v, k) for k, v in weights.items() if k != 'lpips' or lpips_fn is not None)
         if 'lpips' in weights and lpips_fn is None:

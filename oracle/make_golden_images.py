@@ -10,7 +10,6 @@ Build container only.  Import recipe as in make_golden.py, plus empty stub modul
 image_util / metrics_util / run.py but not called by the functions used here (PNG / MP4 encoding and SSIM are NOT
 part of this fixture).
 """
-import io
 import os
 import sys
 import types

@@ -167,3 +167,62 @@ def test_world2_gradients_replicas_and_sharded_render(mode, serial):
         assert a.dtype == np.uint8 and a.shape == (96, 96, 3)
         assert np.array_equal(a, b)
     assert imgs[0].std() > 1.0                             # not an empty image
+
+
+def _rccl_worker(port, q):
+    """One rank, backend 'nccl' (= RCCL): the collectives of GradientSync run for real (over one rank they are
+    identities), inside autograd's backward thread and on the training stream, as they do with one GPU per rank."""
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    import torch.distributed as dist
+    dev = torch.device('cuda:0')
+    torch.cuda.set_device(dev)
+    dist.init_process_group('nccl', rank=0, world_size=1)
+    try:
+        from humannerf_amd.config import cfg
+        from humannerf_amd.train import Trainer
+        cfg.N_samples, cfg.perturb, cfg.train.lossweights.lpips = S_TRAIN, 1.0, 0.0
+        out = {}
+        for mode in ('none', 'volume', 'full'):
+            cfg.amd.ddp_reduce = mode if mode != 'none' else 'volume'
+            cfg.amd.ddp_single_rank_collectives = mode != 'none'
+            net = _net(dev)
+            tr = Trainer(net, world_size=1)
+            assert tr.grad_sync.active == (mode != 'none')
+            tr.iter = 30000
+            losses, g = [], None
+            for _ in range(2):                              # second step: persistent buckets, deferred flags polled
+                loss, _ = tr.backward_step(_train_batch(0, dev))
+                g = _grads(net) if g is None else g          # (compared: the first step's, from identical parameters)
+                tr.optimizer_step()
+                losses.append(float(loss))
+            tr.grad_sync.finish()
+            torch.cuda.synchronize()
+            out[mode] = (g, losses, tr.grad_sync.take_bytes())
+        dist.barrier()
+        q.put(out)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_collectives_run_on_rccl():
+    """The same training step over backend 'nccl' (RCCL) with one rank: results equal the collective-free run, and the
+    byte counters show that the collectives were issued."""
+    port = _free_port()
+    ctx = mp.get_context('spawn')
+    q = ctx.SimpleQueue()
+    p = ctx.Process(target=_rccl_worker, args=(port, q))
+    p.start()
+    out = q.get()
+    p.join(300)
+    assert p.exitcode == 0
+    ref, ref_losses, ref_bytes = out['none']
+    assert ref_bytes == 0
+    for mode in ('volume', 'full'):
+        g, losses, nbytes = out[mode]
+        assert nbytes > 3 * 1024 * 1024, (mode, nbytes)
+        assert np.allclose(losses, ref_losses, rtol=1e-3)
+        for n in ref:
+            assert (g[n] is None) == (ref[n] is None), n
+            if ref[n] is not None:
+                scale = float(np.abs(ref[n]).max())
+                assert float(np.abs(g[n] - ref[n]).max()) <= 2e-5 * scale + 1e-12, (mode, n)

@@ -10,7 +10,6 @@ fp32 tolerance of the build (both MLP arithmetics), stated once -- SURVEY.md sec
 Per-sample colours sit behind a 2^9 positional-encoding band and are compared
 loosely (see tests/test_oracle_golden.py).
 """
-import json
 import os
 
 import numpy as np
@@ -557,8 +556,6 @@ def test_early_ray_termination_is_bounded(gpu_net, mode):
         assert float((both[k] - dense[k]).abs().max()) <= tol, k
         assert float((res[1e-30][k] - dense[k]).abs().max()) <= 2e-6, k
     assert float((res[1e-30]['depth'] - dense['depth']).abs().max()) <= 2e-5
-    # how much work the threshold saves on this frame (direct call on one chunk)
-    from humannerf_amd.network import motion_basis
     assert float((res[1e-3]['rgb'] - dense['rgb']).abs().max()) > 0.0          # the cut really happened
 
 

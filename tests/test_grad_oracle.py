@@ -5,7 +5,6 @@ import json
 import os
 
 import numpy as np
-import pytest
 import torch
 
 from oracle import oracle

@@ -6,7 +6,6 @@ reference vs the fp64 restatement: rgb 1.0e-5, alpha 1.5e-5, depth 9e-5,
 x_skel 6e-5, raw 0.23 (of 98), rgb_on_rays 1e-2 -- the 2^9 positional-encoding
 band amplifies 1e-5 position noise, so per-sample colours are compared
 loosely and the composited per-ray outputs tightly."""
-import json
 import os
 
 import numpy as np
