@@ -181,14 +181,17 @@ class ImageWriter:
     """PNG writer of the render drivers (image_util.py:55-128): ``<output_dir>/<exp_name>/<name or %06d>.png``.
     Encoding runs on ``workers`` threads behind a bounded queue (PIL releases the GIL while it compresses), so
     ``append`` returns at once and can be used as ``render_frames(on_image=...)``; ``finalize`` drains the queue.  The
-    reference's finalize() also writes an MP4 through imageio: imageio is not importable here, so the frames are
-    additionally stacked into ``<exp_name>.npy`` (sorted by name like the reference) and the encoder is left to the user."""
+    reference's finalize() also writes an MP4 through imageio (fps 10, quality 8): done when imageio is importable;
+    it is not in this image, so the frames are then stacked into ``<exp_name>.npy`` (sorted by name like the
+    reference) and the encoder is left to the user.  ``append_3d`` / ``append_cnl_3d`` write the point clouds of
+    run.py's 3-D dumps as Wavefront .obj text exactly like image_util.py:85-109."""
 
     def __init__(self, output_dir, exp_name, workers=4, keep_frames=True):
         from PIL import Image
         self._Image = Image
         self.output_dir = output_dir
         self.image_dir = os.path.join(output_dir, exp_name)
+        self.obj_dir = os.path.join(output_dir, exp_name + '_3d')
         os.makedirs(self.image_dir, exist_ok=True)
         self.frame_idx = -1
         self.keep = keep_frames
@@ -220,6 +223,25 @@ class ImageWriter:
             self.image_names.append(img_name)
         return self.frame_idx, img_name
 
+    def append_3d(self, point3d, mask, obj_name=None, weight_img=None, depth_img=None):
+        """(H, W, 3) positions of the pixels where ``mask`` is set as 'v x y z' lines (image_util.py:85-97)."""
+        os.makedirs(self.obj_dir, exist_ok=True)
+        obj_name = '%06d' % self.frame_idx if obj_name is None else obj_name
+        us, vs = np.nonzero(mask)
+        with open(os.path.join(self.obj_dir, obj_name + '.obj'), 'w') as f:
+            f.writelines('v %.7f %.7f %.7f\n' % tuple(point3d[u, v]) for u, v in zip(us, vs))
+        if weight_img is not None:
+            np.save(os.path.join(self.obj_dir, obj_name + '-weights.npy'), weight_img)
+        if depth_img is not None:
+            np.save(os.path.join(self.obj_dir, obj_name + '-depth.npy'), depth_img)
+
+    def append_cnl_3d(self, cnl_xyz, cnl_rgb, obj_name=None):
+        """Coloured canonical points: 'v x y z r g b ' lines (image_util.py:102-109)."""
+        os.makedirs(self.obj_dir, exist_ok=True)
+        obj_name = '%06d-cnl' % self.frame_idx if obj_name is None else obj_name
+        with open(os.path.join(self.obj_dir, obj_name + '.obj'), 'w') as f:
+            f.writelines('v %.7f %.7f %.7f %.7f %.7f %.7f \n' % (*xyz, *rgb) for xyz, rgb in zip(cnl_xyz, cnl_rgb))
+
     def finalize(self, video_name=None):
         for _ in self._threads:
             self._q.put(None)
@@ -230,6 +252,14 @@ class ImageWriter:
         if self.keep and self.images_np:
             order = sorted(range(len(self.images_np)), key=lambda i: self.image_names[i])
             stack = np.stack([self.images_np[i] for i in order], axis=0)
+            try:
+                import imageio
+            except ImportError:
+                imageio = None
+            if imageio is not None:                                              # image_util.py:122-128
+                path = (self.image_dir.rstrip('/') + '.mp4') if video_name is None else os.path.join(self.image_dir, video_name)
+                imageio.mimwrite(path, stack, format='mp4', fps=10, quality=8)
+                return path
             path = (self.image_dir.rstrip('/') + '.npy') if video_name is None else os.path.join(self.image_dir, video_name + '.npy')
             np.save(path, stack)
             return path

@@ -84,3 +84,19 @@ def test_image_writer_threads(tmp_path):
     assert len(files) == 9 and '000001.png' in files and 'named_00.png' in files
     assert np.array_equal(np.asarray(Image.open(tmp_path / 'freeview' / 'named_04.png')), imgs[4])
     assert np.load(stack).shape == (9, 24, 31, 3)
+
+
+def test_point_cloud_dumps(tmp_path):
+    """append_3d / append_cnl_3d: the .obj text of image_util.py:85-109 (line format checked literally)."""
+    w = render.ImageWriter(str(tmp_path), 'mv', workers=1, keep_frames=False)
+    w.append(np.zeros((4, 5, 3), np.uint8))
+    pts = np.arange(4 * 5 * 3, dtype=np.float32).reshape(4, 5, 3) / 7
+    mask = np.zeros((4, 5), bool)
+    mask[1, 2] = mask[3, 0] = True
+    w.append_3d(pts, mask, depth_img=np.ones((4, 5), np.float32))
+    w.append_cnl_3d(np.array([[0.5, -1.0, 2.0]]), np.array([[0.1, 0.2, 0.3]]))
+    w.finalize()
+    lines = open(tmp_path / 'mv_3d' / '000000.obj').read().splitlines()
+    assert lines == ['v %.7f %.7f %.7f' % tuple(pts[1, 2]), 'v %.7f %.7f %.7f' % tuple(pts[3, 0])]
+    assert open(tmp_path / 'mv_3d' / '000000-cnl.obj').read() == 'v 0.5000000 -1.0000000 2.0000000 0.1000000 0.2000000 0.3000000 \n'
+    assert np.load(tmp_path / 'mv_3d' / '000000-depth.npy').shape == (4, 5)
