@@ -304,6 +304,14 @@ class Subject:
         return out
 
     # -- images -------------------------------------------------------------------------------------------------
+    def image_size(self, frame_name):
+        """(H, W) of a frame after cfg.resize_img_scale, from the PNG header (camera-only rendering needs no pixels)."""
+        from PIL import Image
+        with Image.open(os.path.join(self.image_dir, '%s.png' % frame_name)) as im:
+            w, h = im.size
+        scale = float(cfg.get('resize_img_scale', 1.0))
+        return (h, w) if scale == 1.0 else (int(round(h * scale)), int(round(w * scale)))
+
     def load_image(self, frame_name, bg_color):
         """train.py:351-408 (default branches): alpha-composite the frame over ``bg_color`` (0..255).  Returns
         img (H, W, 3) float in 0..255, alpha (H, W, 3) in 0..1, and 'exact' | 'unpinned' for the resize step."""

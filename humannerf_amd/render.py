@@ -287,7 +287,8 @@ def render_frames(network, frames, rank=0, world=1, device=None, on_image=None, 
 
     Returns {frame_idx: uint8 rgb image on the host} for this rank's frames.  ``on_image(idx, rgb8, alpha8[,
     truth8])`` is called as images arrive (e.g. ``ImageWriter.append``); with ``show_truth`` a frame's ``target_rgbs``
-    (N, 3) are unpacked next to the render (run.py:131-136) and handed over as the fourth argument.
+    (N, 3) -- or, for camera-only frames, the pixels of its ``raw_rgbs`` image (H, W, 3) that the rays hit -- are
+    unpacked next to the render (run.py:131-136) and handed over as the fourth argument.
 
     A frame may carry its camera instead of precomputed rays -- ``K`` (3,3), ``E`` (4,4), ``cnl_bbox_max_xyz`` next to
     ``img_width`` / ``img_height`` and no ``rays``: the rays, near/far and ray_mask are then generated on the
@@ -348,6 +349,8 @@ def render_frames(network, frames, rank=0, world=1, device=None, on_image=None, 
             truth = None
             if show_truth and fr.get('target_rgbs', None) is not None:
                 truth = torch.as_tensor(fr['target_rgbs']).to(device)
+            elif show_truth and fr.get('raw_rgbs', None) is not None:    # whole image (0..1): take the pixels the rays hit
+                truth = torch.as_tensor(np.ascontiguousarray(fr['raw_rgbs'])).to(device).reshape(-1, 3)[mask.reshape(-1)]
             rgb8, a8, t8 = unpack_to_image(int(fr['img_width']), int(fr['img_height']), mask, data['bgcolor'] / 255.,
                                            res['rgb'], res['alpha'], truth)
             imgs = [rgb8, a8] + ([t8] if truth is not None else [])

@@ -655,3 +655,42 @@ def test_subject_directory_renders_end_to_end(gpu_net, golden_dir):
         assert a[i].shape == (64, 48, 3)
         assert np.abs(a[i].astype(np.int32) - b[i].astype(np.int32)).max() <= 1
         assert (a[i] < 250).any()                            # the body is in the picture
+
+
+def test_run_modes_on_a_subject_directory(gpu_net, golden_dir, tmp_path):
+    """humannerf_amd.run: run.py's movement / freeview / tpose loops (run.py:67-183, 212-445) over the synthetic subject
+    directory -- files in the reference's layout, truth panel next to the render, PSNR text files, and the movement
+    render equal to the frame rendered directly from host-side rays."""
+    from PIL import Image
+    from humannerf_amd import dataset, render, run
+    from humannerf_amd.config import cfg
+    subj = dataset.Subject(os.path.join(golden_dir, 'subject_synth'))
+    old = (cfg.amd.diagnostics, cfg.N_samples, cfg.get('show_truth', False), cfg.get('show_alpha', False), cfg.bgcolor)
+    cfg.amd.diagnostics, cfg.N_samples, cfg.show_alpha, cfg.bgcolor = False, 64, False, [255., 255., 255.]
+    try:
+        mv = run.run_movement(gpu_net, subj, logdir=str(tmp_path), metrics=['psnr'])
+        fv = run.run_freeview(gpu_net, subj, frame_idx=1, total_frames=4, logdir=str(tmp_path))
+        cfg.show_alpha = True
+        tp = run.run_tpose(gpu_net, subj, total_frames=3, image_size=64, logdir=str(tmp_path))
+        assert cfg.ignore_non_rigid_motions is False                   # restored
+        host = [subj.movement_frame(i, host_rays=True, load_image=True) for i in range(3)]
+        direct = render.render_frames(gpu_net, host, show_truth=True)
+    finally:
+        cfg.amd.diagnostics, cfg.N_samples, cfg.show_truth, cfg.show_alpha, cfg.bgcolor = old
+    root = tmp_path / 'latest'
+    names = sorted(os.listdir(root / 'movement'))
+    assert names == ['frame_000003.png', 'frame_000010.png', 'frame_000042.png']
+    for i, n in enumerate(names):
+        im = np.asarray(Image.open(root / 'movement' / n))
+        assert im.shape == (64, 2 * 48, 3)                             # render | truth
+        assert np.abs(im[:, :48].astype(np.int32) - direct[i].astype(np.int32)).max() <= 1
+        assert np.array_equal(im[:, :48], mv['images'][i])
+    per_img = open(root / 'movement-metrics.perimg.txt').read()
+    assert 'frame_000010: psnr-' in per_img and mv['metrics']['psnr'] > 3.0
+    assert open(root / 'movement-metrics.average.txt').read().splitlines()[-1].startswith('p:')
+    assert sorted(os.listdir(root / 'freeview_1')) == ['%06d.png' % i for i in range(4)]
+    assert np.asarray(Image.open(root / 'freeview_1' / '000002.png')).shape == (64, 48, 3)
+    assert not np.array_equal(fv['images'][0], fv['images'][2])        # the camera moved
+    t = np.asarray(Image.open(root / 'tpose' / '000001.png'))
+    assert t.shape == (64, 2 * 64, 3)                                  # render | alpha
+    assert (t[:, :64] < 250).any() and t[:, 64:].max() > 100 and len(tp['images']) == 3
