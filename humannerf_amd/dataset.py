@@ -335,12 +335,87 @@ class Subject:
         return res(img, Image.LANCZOS), res(alpha, Image.BILINEAR), 'unpinned'
 
 
-def to_device(batch, device, exclude=('frame_name', 'img_width', 'img_height', 'resize_parity')):
+class FrameStream:
+    """Endless iterator of training batches on the device: what DataLoader(train dataset, batch_size=1, shuffle=True,
+    num_workers=cfg.num_workers) + cpu_data_to_gpu are to the reference's loop (create_dataset.py:73-88,
+    trainer.py:193-199), for one process per GPU.  Every epoch is one seeded permutation of the frames -- the same on
+    all ranks -- of which rank r takes elements r, r + world, ... (wrapping around so that every rank gets the same
+    count: DistributedSampler's rule).  ``workers`` threads assemble frames ahead of the consumer (PNG decoding and the
+    numpy ray / patch code release the GIL for most of their time), ``prefetch`` batches are kept ready; uploads go
+    through pinned memory so that they overlap the step that is running."""
+
+    def __init__(self, subject, rank=0, world=1, seed=0, device=None, prefetch=3, workers=2, bgcolor=None):
+        import threading
+        self.subject, self.rank, self.world, self.seed = subject, int(rank), int(world), int(seed)
+        self.device, self.bgcolor = device, bgcolor
+        self._done = {}
+        self._cv = threading.Condition()
+        self._next_put, self._next_get, self._stop = 0, 0, False
+        self._order = self._indices()
+        self._threads = [threading.Thread(target=self._work, daemon=True) for _ in range(max(1, workers))]
+        self._slots = threading.Semaphore(max(1, prefetch))
+        self._err = None
+        for t in self._threads:
+            t.start()
+
+    def _indices(self):
+        epoch = 0
+        while True:
+            n = len(self.subject)
+            perm = np.random.RandomState(self.seed + epoch).permutation(n)
+            per_rank = -(-n // self.world)
+            padded = np.resize(perm, per_rank * self.world)
+            for i in padded[self.rank::self.world]:
+                yield int(i)
+            epoch += 1
+
+    def _work(self):
+        while True:
+            self._slots.acquire()
+            with self._cv:
+                if self._stop:
+                    return
+                ticket, idx = self._next_put, next(self._order)
+                self._next_put += 1
+            try:
+                item = self.subject.train_frame(idx, bgcolor=self.bgcolor)
+            except Exception as e:                                   # surfaced by __next__
+                item = e
+            with self._cv:
+                self._done[ticket] = item
+                self._cv.notify_all()
+
+    def __iter__(self):
+        return self
+
+    def __next__(self):
+        with self._cv:
+            while self._next_get not in self._done:
+                self._cv.wait()
+            item = self._done.pop(self._next_get)
+            self._next_get += 1
+        self._slots.release()
+        if isinstance(item, Exception):
+            self.close()
+            raise item
+        return to_device(item, self.device, pinned=True) if self.device is not None else item
+
+    def close(self):
+        with self._cv:
+            self._stop = True
+        for _ in self._threads:
+            self._slots.release()
+
+
+def to_device(batch, device, exclude=('frame_name', 'img_width', 'img_height', 'resize_parity'), pinned=False):
     """cpu_data_to_gpu (train_util.py:7-25): tensors of everything but the excluded keys."""
     import torch
     out = {}
     for k, v in batch.items():
         if k in exclude or isinstance(v, str):
             continue
-        out[k] = torch.as_tensor(np.ascontiguousarray(v) if isinstance(v, np.ndarray) else v).to(device)
+        t = torch.as_tensor(np.ascontiguousarray(v) if isinstance(v, np.ndarray) else v)
+        if pinned and torch.device(device).type == 'cuda' and t.numel() > 0:
+            t = t.pin_memory()
+        out[k] = t.to(device, non_blocking=pinned)
     return out

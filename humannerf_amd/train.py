@@ -281,6 +281,41 @@ def make_progress_fn(frames, logdir, device=None, imgs_per_row=4):
     return progress
 
 
+def train_subject(network, subject, logdir, rank=0, world=1, device=None, maxiter=None, lpips_fn=None, seed=None,
+                  progress=True, log_fn=print):
+    """What the reference's train.py main() does (train.py:17-40, trainer.py:46-75, 177-184) for one prepared subject
+    directory, one process per GPU: resume from ``<logdir>/<cfg.load_net>.tar`` when cfg.resume is set and it exists
+    (otherwise save 'init'), stream shuffled frames of this rank's shard (dataset.FrameStream), step until
+    cfg.train.maxiter with the progress mosaic of 16 evenly spaced frames (create_dataset.py:47-52) and the
+    checkpoint cadence of Trainer.train, save 'latest' at the end (trainer.py:352-354).  Returns the Trainer."""
+    from . import dataset
+    device = device or next(network.parameters()).device
+    seed = int(cfg.get('random_seed', 0) if seed is None else seed)
+    torch.manual_seed(seed + rank)
+    trainer = Trainer(network, lpips_fn=lpips_fn, world_size=world, logdir=logdir)
+    name = str(cfg.get('load_net', 'latest'))
+    if cfg.get('resume', False) and os.path.isfile(os.path.join(logdir, name + '.tar')):
+        trainer.load_ckpt(name, map_location=device)
+    elif rank == 0:
+        trainer.iter = 0
+        trainer.save_ckpt('init')
+        trainer.iter = 1
+    progress_fn = None
+    if progress and rank == 0:
+        total = len(subject.framelist_all)
+        prog = dataset.Subject(subject.dataset_path, skip=max(1, total // 16), maxframes=16)
+        frames = [prog.movement_frame(i, load_image=True) for i in range(len(prog))]
+        progress_fn = make_progress_fn(frames, logdir, device=device)
+    stream = dataset.FrameStream(subject, rank=rank, world=world, seed=seed, device=device)
+    try:
+        trainer.train(stream, maxiter=maxiter, progress_fn=progress_fn, log_fn=log_fn if rank == 0 else None, rank=rank)
+    finally:
+        stream.close()
+    if rank == 0:
+        trainer.save_ckpt('latest')                                 # Trainer.finalize (trainer.py:257-258)
+    return trainer
+
+
 def load_checkpoint(path, map_location=None):
     """Read a ``.tar`` checkpoint of the reference's layout ({'iter', 'network', 'optimizer'}, trainer.py:356-364)
     without executing anything from the file (``weights_only=True``)."""

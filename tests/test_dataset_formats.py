@@ -172,3 +172,29 @@ def test_checkpoint_tar_reader(tmp_path):
     torch.save({'something': 1}, path)
     with pytest.raises(ValueError):
         load_checkpoint(path)
+
+
+def test_frame_stream_shards_and_shuffles(subj):
+    """FrameStream: every epoch is one permutation shared by the ranks, rank r takes every world-th element (wrapping,
+    DistributedSampler's rule); batches arrive in that order whatever the worker threads do."""
+    from humannerf_amd import dataset
+    from humannerf_amd.config import cfg
+    old = (cfg.patch.N_patches, cfg.patch.size)
+    cfg.patch.N_patches, cfg.patch.size = 2, 16
+    try:
+        streams = [dataset.FrameStream(subj, rank=r, world=2, seed=5, workers=3, bgcolor=(0., 0., 0.)) for r in range(2)]
+        got = [[next(s)['frame_name'] for _ in range(4)] for s in streams]
+        for s in streams:
+            s.close()
+    finally:
+        cfg.patch.N_patches, cfg.patch.size = old
+    names = subj.framelist
+    for epoch in range(2):
+        perm = [names[i] for i in np.random.RandomState(5 + epoch).permutation(3)]
+        padded = perm + perm[:1]                                          # 3 frames over 2 ranks: wrap to 4
+        assert got[0][2 * epoch:2 * epoch + 2] == padded[0::2]
+        assert got[1][2 * epoch:2 * epoch + 2] == padded[1::2]
+    one = dataset.FrameStream(subj, seed=1, bgcolor=(0., 0., 0.))
+    b = next(one)
+    one.close()
+    assert b['rays'].shape[0] == 3 and b['target_patches'].ndim == 4 and b['patch_masks'].dtype == bool

@@ -187,3 +187,42 @@ def test_operand_range_guard_raises_in_training(seeded_params):
         cfg.N_samples, cfg.train.lossweights.lpips, cfg.amd.train_check_every = old
         cfg.amd.train_mlp_mode = cfg.amd.train_chain_mode = cfg.amd.train_dw_mode = 'f16x3'
         autograd.range_guard.calls, autograd.range_guard.pending = 0, []
+
+
+def test_train_subject_from_a_directory(tmp_path, seeded_params, golden_dir):
+    """train.train_subject = the reference's train.py main() over a prepared subject directory: 'init' checkpoint,
+    shuffled patch batches through FrameStream, progress mosaic of the subject's frames, 'latest' at the end; a second
+    call with cfg.resume continues at the next iteration with the optimizer state."""
+    import os
+    from humannerf_amd import dataset
+    from humannerf_amd.config import cfg
+    from humannerf_amd.network import Network
+    from humannerf_amd.train import load_checkpoint, train_subject
+    dev = torch.device('cuda:0')
+    old = (cfg.patch.N_patches, cfg.patch.size, cfg.N_samples, cfg.train.lossweights.lpips, cfg.get('resume', False),
+           cfg.train.log_interval)
+    cfg.patch.N_patches, cfg.patch.size, cfg.N_samples, cfg.train.lossweights.lpips = 3, 16, 32, 0.0
+    cfg.train.log_interval = 1
+    try:
+        subj = dataset.Subject(os.path.join(golden_dir, 'subject_synth'))
+        net = Network()
+        net.load_state_dict({k: torch.from_numpy(v) for k, v in seeded_params.items()})
+        logs = []
+        cfg.resume = False
+        tr = train_subject(net.to(dev), subj, str(tmp_path), maxiter=3, log_fn=logs.append)
+        assert tr.iter == 4 and len(logs) == 3 and all(np.isfinite(float(l.split('Loss: ')[1].split()[0])) for l in logs)
+        assert {'init.tar', 'latest.tar', 'prog_000001.jpg'} <= set(os.listdir(tmp_path))
+        assert load_checkpoint(str(tmp_path / 'init.tar'))['iter'] == 0
+        ck = load_checkpoint(str(tmp_path / 'latest.tar'))
+        assert ck['iter'] == 4 and set(ck) == {'iter', 'network', 'optimizer'}
+        w_after = {k: v.clone() for k, v in tr.network.state_dict().items()}
+        moved = [k for k, v in w_after.items() if not torch.equal(v.cpu(), torch.from_numpy(seeded_params[k]))]
+        assert len(moved) >= 50                                              # every trainable tensor was stepped
+        cfg.resume = True
+        tr2 = train_subject(Network().to(dev), subj, str(tmp_path), maxiter=6, progress=False, log_fn=None)
+        assert tr2.start_iter == 5 and tr2.iter == 7
+        st = tr2.optimizer.state_dict()['state']
+        assert float(st[0]['step']) == 3 + 2                                # 3 steps restored + iterations 5 and 6
+    finally:
+        (cfg.patch.N_patches, cfg.patch.size, cfg.N_samples, cfg.train.lossweights.lpips, cfg.resume,
+         cfg.train.log_interval) = old
