@@ -335,6 +335,100 @@ class Subject:
         return res(img, Image.LANCZOS), res(alpha, Image.BILINEAR), 'unpinned'
 
 
+class DeviceFrameCache:
+    """Training items assembled on the device from per-frame data that stays resident in HBM.
+
+    Everything Subject.train_frame computes except the random choices is a constant of the frame: the rays of the
+    whole image, near / far, the bbox hit mask, the image and its alpha.  The numpy route recomputes all of it for
+    every item (262 144 rays generated and slab-tested to keep 6 144: 230 ms per item on this container's cores --
+    4 items/s per loader thread against a training step of 11 ms).  Here a frame's constants are built once --
+    hnrf_gen_rays on the device (same hit mask, rays within 1 ulp of the numpy helpers:
+    tests/test_gpu_parity.py::test_ray_generation_kernel), PNGs decoded once -- and kept on the GPU (11 MB per
+    512x512 frame: a 650-frame ZJU subject is 7 GB of the 288); an item then costs the reference's patch draw on the
+    host (scene.PatchSampler: same numpy generator calls, same result) and a few gathers / 32x32 crops on the device.
+
+    ``train_batch(idx)`` returns what ``to_device(subject.train_frame(idx))`` returns, equal value for value given the
+    same state of the global numpy generator (tests/test_gpu_parity.py::test_device_frame_cache_equals_host_route)."""
+
+    def __init__(self, subject, device, max_bytes=64 << 30):
+        self.subject, self.device, self.max_bytes = subject, device, int(max_bytes)
+        self.entries, self.bytes = {}, 0
+        import threading
+        self._lock = threading.Lock()
+
+    def _build(self, idx):
+        import torch
+        from . import ops
+        from PIL import Image
+        subj, dev = self.subject, self.device
+        name = subj.framelist[idx]
+        info, cam = subj.mesh_infos[name], subj.cameras[name]
+        if float(cfg.get('resize_img_scale', 1.0)) != 1.0:
+            raise NotImplementedError('DeviceFrameCache keeps the PNGs as decoded: resize the images offline or use '
+                                      'Subject.train_frame (cfg.resize_img_scale = %s)' % cfg.resize_img_scale)
+        if 'distortions' in cam and np.any(np.asarray(cam['distortions']) != 0):
+            raise NotImplementedError('frame %s has lens distortion: undistort the images offline' % name)
+        orig = np.array(Image.open(os.path.join(subj.image_dir, '%s.png' % name)).convert('RGB'))
+        alpha = np.array(Image.open(os.path.join(subj.dataset_path, 'masks', '%s.png' % name)).convert('RGB'))
+        if alpha.max() == 1:
+            alpha = alpha * 255
+        H, W = orig.shape[:2]
+        K = cam['intrinsics'][:3, :3].copy()
+        E = apply_global_tfm_to_camera(cam['extrinsics'], info['Rh'].astype('float32'), info['Th'].astype('float32'))
+        bbox = info['bbox']
+        with torch.cuda.device(dev):
+            g = ops.gen_rays(K.astype('float32'), E.astype('float32'), np.asarray(bbox['min_xyz'], 'float32'),
+                             np.asarray(bbox['max_xyz'], 'float32'), H, W, device=dev)
+        ray_mask = g['ray_mask'].cpu().numpy()
+        ent = {'name': name, 'H': H, 'W': W,
+               'rays': g['rays'][:2].contiguous(), 'near': g['near'].contiguous(), 'far': g['far'].contiguous(),
+               'ray_mask': g['ray_mask'],
+               'orig': torch.from_numpy(orig).to(dev), 'alpha': torch.from_numpy(alpha.astype(np.uint8)).to(dev),
+               'sampler': scene.PatchSampler(ray_mask, alpha[:, :, 0] > 0, ray_mask.reshape(H, W), H, W),
+               'skeleton': {k: torch.as_tensor(np.ascontiguousarray(v)).to(dev)
+                            for k, v in subj._skeleton_entries(info).items()}}
+        ent['bytes'] = sum(v.numel() * v.element_size() for v in ent.values() if torch.is_tensor(v))
+        return ent
+
+    def entry(self, idx):
+        with self._lock:
+            ent = self.entries.get(idx)
+        if ent is None:
+            ent = self._build(idx)
+            with self._lock:
+                if idx not in self.entries and self.bytes + ent['bytes'] <= self.max_bytes:
+                    self.entries[idx] = ent
+                    self.bytes += ent['bytes']
+        return ent
+
+    def train_batch(self, idx, bgcolor=None):
+        import torch
+        ent, dev = self.entry(idx), self.device
+        # the two random draws of an item, in train_frame's order: background colour, then the patches
+        bg = (np.random.rand(3) * 255.).astype('float32') if bgcolor is None else np.array(bgcolor, dtype='float32')
+        sel, pinfo, div = ent['sampler'].draw(int(cfg.patch.N_patches), int(cfg.patch.size),
+                                              subject_ratio=float(cfg.patch.sample_subject_ratio))
+        sel_d = torch.from_numpy(sel.astype(np.int64)).to(dev, non_blocking=True)
+        masks_d = torch.from_numpy(pinfo['mask']).to(dev, non_blocking=True)
+        bg_d = torch.from_numpy(bg).to(dev, non_blocking=True)
+        # (positions of the kept pixels inside the stacked patches, found on the host: a boolean index on the device
+        # would read the count back)
+        flat_d = torch.from_numpy(np.flatnonzero(pinfo['mask'])).to(dev, non_blocking=True)
+        o, d = ent['rays'][0].index_select(0, sel_d), ent['rays'][1].index_select(0, sel_d)
+        crops_o = torch.stack([ent['orig'][y0:y1, x0:x1] for (x0, y0), (x1, y1) in zip(pinfo['xy_min'], pinfo['xy_max'])])
+        crops_a = torch.stack([ent['alpha'][y0:y1, x0:x1] for (x0, y0), (x1, y1) in zip(pinfo['xy_min'], pinfo['xy_max'])])
+        a = crops_a.double() / 255.
+        # float64 like the numpy route (load_image), rounded to float32 once at the end
+        targets = ((a * crops_o.double() + (1.0 - a) * bg_d.double()) / 255.).float()
+        out = {'frame_name': ent['name'], 'bgcolor': bg_d, 'img_width': ent['W'], 'img_height': ent['H'],
+               'ray_mask': ent['ray_mask'], 'rays': torch.stack([o, d, d], 0),
+               'near': ent['near'].index_select(0, sel_d), 'far': ent['far'].index_select(0, sel_d),
+               'patch_div_indices': torch.from_numpy(div), 'patch_masks': masks_d, 'target_patches': targets,
+               'target_rgbs': targets.reshape(-1, 3).index_select(0, flat_d), 'resize_parity': 'exact'}
+        out.update(ent['skeleton'])
+        return out
+
+
 class FrameStream:
     """Endless iterator of training batches on the device: what DataLoader(train dataset, batch_size=1, shuffle=True,
     num_workers=cfg.num_workers) + cpu_data_to_gpu are to the reference's loop (create_dataset.py:73-88,
@@ -344,8 +438,14 @@ class FrameStream:
     numpy ray / patch code release the GIL for most of their time), ``prefetch`` batches are kept ready; uploads go
     through pinned memory so that they overlap the step that is running."""
 
-    def __init__(self, subject, rank=0, world=1, seed=0, device=None, prefetch=3, workers=2, bgcolor=None):
+    def __init__(self, subject, rank=0, world=1, seed=0, device=None, prefetch=3, workers=2, bgcolor=None,
+                 device_cache=None):
         import threading
+        import torch
+        if device_cache is None:                      # default: frames stay resident on a GPU (DeviceFrameCache)
+            device_cache = device is not None and torch.device(device).type == 'cuda' and \
+                float(cfg.get('resize_img_scale', 1.0)) == 1.0
+        self.cache = DeviceFrameCache(subject, device) if device_cache else None
         self.subject, self.rank, self.world, self.seed = subject, int(rank), int(world), int(seed)
         self.device, self.bgcolor = device, bgcolor
         self._done = {}
@@ -378,7 +478,12 @@ class FrameStream:
                 ticket, idx = self._next_put, next(self._order)
                 self._next_put += 1
             try:
-                item = self.subject.train_frame(idx, bgcolor=self.bgcolor)
+                if self.cache is not None:
+                    import torch
+                    with torch.cuda.device(self.device):
+                        item = self.cache.train_batch(idx, bgcolor=self.bgcolor)
+                else:
+                    item = self.subject.train_frame(idx, bgcolor=self.bgcolor)
             except Exception as e:                                   # surfaced by __next__
                 item = e
             with self._cv:
@@ -398,6 +503,9 @@ class FrameStream:
         if isinstance(item, Exception):
             self.close()
             raise item
+        if self.cache is not None:
+            exclude = ('frame_name', 'img_width', 'img_height', 'resize_parity')
+            return {k: v for k, v in item.items() if k not in exclude}
         return to_device(item, self.device, pinned=True) if self.device is not None else item
 
     def close(self):
@@ -407,12 +515,18 @@ class FrameStream:
             self._slots.release()
 
 
-def to_device(batch, device, exclude=('frame_name', 'img_width', 'img_height', 'resize_parity'), pinned=False):
-    """cpu_data_to_gpu (train_util.py:7-25): tensors of everything but the excluded keys."""
+def to_device(batch, device, exclude=('frame_name', 'img_width', 'img_height', 'resize_parity'), pinned=False,
+              host_keys=('patch_div_indices',)):
+    """cpu_data_to_gpu (train_util.py:7-25): tensors of everything but the excluded keys.  ``host_keys`` become tensors
+    but stay on the host: the patch boundaries are read as Python ints by the loss (trainer.py:28-37) -- on the device
+    every one of them would be a synchronisation."""
     import torch
     out = {}
     for k, v in batch.items():
         if k in exclude or isinstance(v, str):
+            continue
+        if k in host_keys:
+            out[k] = torch.as_tensor(v)
             continue
         t = torch.as_tensor(np.ascontiguousarray(v) if isinstance(v, np.ndarray) else v)
         if pinned and torch.device(device).type == 'cuda' and t.numel() > 0:

@@ -216,6 +216,40 @@ def sample_patch_rays(ray_mask, subject_mask, bbox_mask, n_patch, patch_size, H,
             np.array(div))
 
 
+class PatchSampler:
+    """sample_patch_rays for ONE frame drawn many times: the candidate pixel lists, the pixel -> ray index map and the
+    2-D hit mask are built once, a draw touches only the n_patch windows.  Same calls on the global numpy generator in
+    the same order (one ``rand``, one ``choice(n, size=[1], replace=False)`` per patch), same outputs as
+    sample_patch_rays -- tests/test_host_cpu.py checks equality draw for draw."""
+
+    def __init__(self, ray_mask, subject_mask, bbox_mask, H, W):
+        assert ray_mask.dtype == bool and subject_mask.dtype == bool and bbox_mask.dtype == bool and ray_mask.ndim == 1
+        self.H, self.W = H, W
+        self.hit = ray_mask.reshape(H, W)
+        self.compact_index = (np.cumsum(ray_mask) - 1).reshape(H, W)
+        self.on = np.where(subject_mask)
+        self.off = np.where(bbox_mask & ~subject_mask)
+
+    def draw(self, n_patch, patch_size, subject_ratio=0.8):
+        H, W = self.H, self.W
+        inds, masks, xy_min, xy_max, div = [], [], [], [], [0]
+        for _ in range(n_patch):
+            ys, xs = self.on if np.random.rand(1)[0] < subject_ratio else self.off
+            pick = np.random.choice(ys.shape[0], size=[1], replace=False)[0]
+            half = patch_size // 2
+            x0 = np.clip(xs[pick] - half, 0, W - patch_size)
+            y0 = np.clip(ys[pick] - half, 0, H - patch_size)
+            hit = self.hit[y0:y0 + patch_size, x0:x0 + patch_size]
+            inds.append(self.compact_index[y0:y0 + patch_size, x0:x0 + patch_size][hit])     # row-major, like np.where
+            masks.append(hit.copy())
+            xy_min.append(np.array([x0, y0]))
+            xy_max.append(np.array([x0 + patch_size, y0 + patch_size]))
+            div.append(div[-1] + len(inds[-1]))
+        return (np.concatenate(inds, axis=0),
+                {'mask': np.stack(masks, axis=0), 'xy_min': np.stack(xy_min, axis=0), 'xy_max': np.stack(xy_max, axis=0)},
+                np.array(div))
+
+
 def tpose_camera(img_size, radius=6.0, focal=1250.0):
     """Orbit camera of the reference's T-pose renderer
     (core/data/human_nerf/tpose.py:65-84)."""

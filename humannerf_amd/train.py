@@ -101,13 +101,15 @@ def update_lr(optimizer, iter_step):
 
 
 def unpack_patches(rgbs, patch_masks, bgcolor, targets, div_indices):
-    """(sum_rays, 3) rendered colours -> (N_patch, H, W, 3) images, background elsewhere (trainer.py:28-37)."""
+    """(sum_rays, 3) rendered colours -> (N_patch, H, W, 3) images, background elsewhere (trainer.py:28-37).  The rays
+    arrive patch after patch, row-major inside a patch -- the order in which a boolean index walks ``patch_masks`` -- so
+    one masked scatter places them all; a boolean-index assignment per patch (the reference's loop) would cost a
+    device synchronisation each."""
     n_patch = len(div_indices) - 1
     assert patch_masks.shape[0] == n_patch and targets.shape[0] == n_patch
+    assert int(div_indices[-1]) == rgbs.shape[0]
     imgs = bgcolor.expand(targets.shape).clone()
-    for i in range(n_patch):
-        imgs[i, patch_masks[i]] = rgbs[int(div_indices[i]):int(div_indices[i + 1])]
-    return imgs
+    return imgs.masked_scatter_(patch_masks[..., None].expand_as(imgs), rgbs)
 
 
 def image_loss(rgb, target, lpips_fn=None):

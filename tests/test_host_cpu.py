@@ -248,3 +248,25 @@ def test_trainer_states_mse_only_objective():
         warnings.simplefilter('always')
         tr = Trainer(net)
     assert any('lpips' in str(x.message) for x in w) and tr.objective == '0.2*mse'
+
+
+def test_patch_sampler_equals_reference_sampler_draw_for_draw():
+    """scene.PatchSampler (per-frame constants cached) vs scene.sample_patch_rays (pinned bit for bit to the
+    reference's sampler by tests/golden/patches_s96.npz): same generator calls, same outputs."""
+    from humannerf_amd import scene
+    H, W = 96, 80
+    yy, xx = np.mgrid[0:H, 0:W]
+    bbox = (yy > 10) & (yy < 90) & (xx > 5) & (xx < 70)
+    subj = (yy - 50) ** 2 / 900 + (xx - 40) ** 2 / 300 < 1
+    ray_mask = bbox.reshape(-1)
+    ps = scene.PatchSampler(ray_mask, subj, bbox, H, W)
+    for seed in range(6):
+        np.random.seed(seed)
+        a = scene.sample_patch_rays(ray_mask, subj, bbox, 6, 32, H, W, subject_ratio=0.7)
+        state_a = np.random.get_state()[1].copy()
+        np.random.seed(seed)
+        b = ps.draw(6, 32, subject_ratio=0.7)
+        assert np.array_equal(np.random.get_state()[1], state_a)          # the generator advanced identically
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[2], b[2])
+        for k in a[1]:
+            assert np.array_equal(a[1][k], b[1][k]), k
