@@ -124,6 +124,10 @@ def main():
 
     for _ in range(args.warmup):
         step()
+    # what a render / training loop of the package does on entry (render_frames, Trainer.train): a full pass of Python's
+    # cyclic GC over the ~10^6 live objects costs ~90 ms and would otherwise land at a random place of a timed region
+    from humannerf_amd.config import quiet_gc
+    quiet_gc()
     net.mlp_event_log = []
     torch.cuda.synchronize()
     if dist is not None:

@@ -39,6 +39,9 @@ SIGNATURES = {
     'hnrf_motion_basis_bwd': (_int, [_vp, _vp, _vp, _vp, _vp, _int, _vp, _vp, _vp, _vp]),
     'hnrf_refined_motion_basis_fwd': (_int, [_vp, _vp, _vp, _vp, _int, _vp, _vp, _vp, _vp]),
     'hnrf_refined_motion_basis_bwd': (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _int, _vp, _vp, _vp, _vp, _vp]),
+    'hnrf_pose_mlp_saved_bytes': (_sz, [_int]),
+    'hnrf_pose_mlp_fwd': (_int, [_vp, _vp, _vp, _vp, _int, _vp, _vp, _vp]),
+    'hnrf_pose_mlp_bwd': (_int, [_vp, _vp, _vp, _vp, _vp, _int, _vp, _vp, _vp, _vp, _vp]),
     'hnrf_mlp_dw_h_workspace_bytes': (_sz, [_i64, _int, _int]),
     'hnrf_mlp_dw_h': (_int, [_vp, _i64, _vp, _i64, _i64, _int, _int, _int, _vp, _vp, _i64, _vp, _vp, _sz, _vp]),
     'hnrf_canonical_bwd_packed_bytes': (_sz, [_int]),

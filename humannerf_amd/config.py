@@ -158,8 +158,28 @@ _DEFAULTS = {
         # run the collectives of the training step even when world_size == 1 (identities over a one-rank group):
         # exercises the RCCL code path on a single-GPU box (tests/test_gpu_dist.py)
         'ddp_single_rank_collectives': False,
+        # gc.freeze() at the start of the training / render loops (config.quiet_gc)
+        'freeze_gc': True,
     },
 }
+
+
+_GC_FROZEN = False
+
+
+def quiet_gc():
+    """Take the objects that exist now (modules, the network, the autograd / ctypes machinery: ~10^6 of them) out of the
+    cyclic garbage collector's generations.  A full collection otherwise walks all of them every few thousand
+    allocations: measured 90-100 ms once per ~138 training steps (0.65 ms per step, 5 %) and the same stall at random
+    places in a render loop.  Called once per process by the loops of train.py / render.py and by bench.py; the collector
+    stays enabled for what is allocated afterwards.  cfg.amd.freeze_gc = False turns it off."""
+    global _GC_FROZEN
+    if _GC_FROZEN or not amd_option('freeze_gc', True):
+        return
+    import gc
+    gc.collect()
+    gc.freeze()
+    _GC_FROZEN = True
 
 
 def get_cfg_defaults():

@@ -224,9 +224,139 @@ __global__ __launch_bounds__(64) void motion_basis_bwd_kernel(const float* __res
     }
 }
 
+// ---- the pose refiner's MLP (BodyPoseRefiner.block_mlps, pose_decoders/mlp_delta_body_pose.py:14-41) -------------------
+// 69 -> 256 -> 256 -> 256 -> 256 -> 69 on ONE vector per frame: in PyTorch 5 GEMV launches + bias / ReLU kernels forward
+// and ~25 launches backward (0.6 ms of a training step for 0.5 MFLOP).  One small launch per layer each way (a
+// single-workgroup version of the whole MLP was tried first: latency-bound, 0.5 ms -- no better than PyTorch): forward
+// one wave per output row; backward one launch per layer on a (column block, row block) grid that writes dW and the
+// row-block partial sums of W^T dz, which the next launch folds together with relu' while it loads its dz
+// (fixed order: deterministic).
+constexpr int PMLP_MAX_LAYERS = 9;
+constexpr int PMLP_MAX_WIDTH = 256;
+constexpr int PMLP_RB = 32;                                       // rows per block of the backward grid
+constexpr int PMLP_MAX_PARTS = PMLP_MAX_WIDTH / PMLP_RB;
+
+// out[r] = act(b[r] + W[r, :] . x): one wave per row, 4 rows per workgroup
+__global__ __launch_bounds__(256) void pose_layer_fwd_kernel(const float* __restrict__ W, const float* __restrict__ b,
+                                                             const float* __restrict__ x, int ni, int no, int relu,
+                                                             float* __restrict__ out, float* __restrict__ out2) {
+    const int lane = threadIdx.x & 63, r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= no) return;
+    float acc = 0.f;
+    for (int k = lane; k < ni; k += 64) acc = fmaf(W[(size_t)r * ni + k], x[k], acc);
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) acc += __shfl_xor(acc, o, 64);
+    if (lane == 0) {
+        float v = acc + b[r];
+        if (relu) v = fmaxf(v, 0.f);
+        out[r] = v;
+        if (out2 != nullptr) out2[r] = v;
+    }
+}
+
+// One layer of the backward.  dz[j] = relu'(h_out[j]) * sum_p part_in[p][j]  (h_out null: no relu', top layer).
+// Block (cb, rb): columns 64 cb .. +63, rows 32 rb .. +31; thread (c, q) takes rows q, q + 4, ... of the row block.
+//   dW[j][k] = dz[j] h_in[k];  db[j] = dz[j] (cb == 0);  part_out[rb][k] = sum_{j in row block} W[j][k] dz[j].
+__global__ __launch_bounds__(256) void pose_layer_bwd_kernel(const float* __restrict__ W, const float* __restrict__ part_in,
+                                                             int nparts_in, const float* __restrict__ h_out,
+                                                             const float* __restrict__ h_in, int ni, int no,
+                                                             float* __restrict__ dW, float* __restrict__ db,
+                                                             float* __restrict__ part_out) {
+    __shared__ float dz[PMLP_RB];
+    __shared__ float red[4][64];
+    const int c = threadIdx.x & 63, q = threadIdx.x >> 6;
+    const int k = blockIdx.x * 64 + c, j0 = blockIdx.y * PMLP_RB;
+    if (threadIdx.x < PMLP_RB) {
+        const int j = j0 + threadIdx.x;
+        float g = 0.f;
+        if (j < no) {
+            for (int p = 0; p < nparts_in; ++p) g += part_in[p * PMLP_MAX_WIDTH + j];
+            if (h_out != nullptr && !(h_out[j] > 0.f)) g = 0.f;
+            if (blockIdx.x == 0) db[j] = g;
+        }
+        dz[threadIdx.x] = g;
+    }
+    __syncthreads();
+    float acc = 0.f;
+    if (k < ni) {
+        const float hk = h_in[k];
+#pragma unroll
+        for (int i = 0; i < PMLP_RB / 4; ++i) {
+            const int jj = q + 4 * i, j = j0 + jj;
+            if (j < no) {
+                const float g = dz[jj];
+                acc = fmaf(W[(size_t)j * ni + k], g, acc);
+                dW[(size_t)j * ni + k] = g * hk;
+            }
+        }
+    }
+    red[q][c] = acc;
+    __syncthreads();
+    if (q == 0 && k < ni) part_out[blockIdx.y * PMLP_MAX_WIDTH + k] = (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]);
+}
+
 }  // namespace hnrf
 
 using namespace hnrf;
+
+static int pose_mlp_args(const char* who, const float* const* W, const float* const* b, const int* dims, int layers) {
+    HNRF_REQUIRE(W && b && dims, HNRF_E_ARG, "%s: null pointer", who);
+    HNRF_REQUIRE(layers >= 1 && layers <= PMLP_MAX_LAYERS, HNRF_E_UNSUPPORTED, "%s: %d layers (built: 1..%d)", who, layers,
+                 PMLP_MAX_LAYERS);
+    for (int l = 0; l <= layers; ++l)
+        HNRF_REQUIRE(dims[l] >= 1 && dims[l] <= PMLP_MAX_WIDTH, HNRF_E_UNSUPPORTED, "%s: width %d (built: 1..%d)", who, dims[l],
+                     PMLP_MAX_WIDTH);
+    for (int l = 0; l < layers; ++l) HNRF_REQUIRE(W[l] && b[l], HNRF_E_ARG, "%s: null layer %d", who, l);
+    return HNRF_OK;
+}
+
+// saved = [hidden activations: (layers - 1) x 256 | backward scratch: 2 x 8 x 256 partial sums] floats
+extern "C" size_t hnrf_pose_mlp_saved_bytes(int layers) {
+    return layers >= 1 && layers <= PMLP_MAX_LAYERS
+               ? (size_t)((layers - 1) + 2 * PMLP_MAX_PARTS) * PMLP_MAX_WIDTH * sizeof(float)
+               : 0;
+}
+
+extern "C" int hnrf_pose_mlp_fwd(const float* x, const float* const* W, const float* const* b, const int* dims, int layers,
+                                 float* out, float* saved, void* stream) {
+    if (int rc = pose_mlp_args("hnrf_pose_mlp_fwd", W, b, dims, layers)) return rc;
+    HNRF_REQUIRE(x && out && (saved || layers == 1), HNRF_E_ARG, "hnrf_pose_mlp_fwd: null pointer");
+    const float* in = x;
+    for (int l = 0; l < layers; ++l) {
+        const bool hidden = l + 1 < layers;
+        float* dst = hidden ? saved + (size_t)l * PMLP_MAX_WIDTH : out;
+        hipLaunchKernelGGL(pose_layer_fwd_kernel, dim3((dims[l + 1] + 3) / 4), dim3(256), 0, (hipStream_t)stream, W[l], b[l], in,
+                           dims[l], dims[l + 1], hidden ? 1 : 0, dst, (float*)nullptr);
+        in = dst;
+    }
+    return check_launch("hnrf_pose_mlp_fwd");
+}
+
+extern "C" int hnrf_pose_mlp_bwd(const float* g_out, const float* x, const float* const* W, const float* const* b,
+                                 const int* dims, int layers, float* saved, float* const* dW, float* const* db,
+                                 float* d_x_parts, void* stream) {
+    if (int rc = pose_mlp_args("hnrf_pose_mlp_bwd", W, b, dims, layers)) return rc;
+    HNRF_REQUIRE(g_out && x && dW && db && saved, HNRF_E_ARG, "hnrf_pose_mlp_bwd: null pointer");
+    for (int l = 0; l < layers; ++l)
+        HNRF_REQUIRE(dW[l] && db[l], HNRF_E_ARG, "hnrf_pose_mlp_bwd: null gradient buffer of layer %d", l);
+    float* scratch = saved + (size_t)(layers - 1) * PMLP_MAX_WIDTH;
+    const float* part_in = g_out;
+    int nparts = 1;
+    for (int l = layers - 1; l >= 0; --l) {
+        const int ni = dims[l], no = dims[l + 1];
+        const float* h_out = l + 1 < layers ? saved + (size_t)l * PMLP_MAX_WIDTH : nullptr;
+        const float* h_in = l == 0 ? x : saved + (size_t)(l - 1) * PMLP_MAX_WIDTH;
+        // layer 0's partial sums of W^T dz are d_x (folded by the caller if it wants them); ping-pong otherwise
+        float* part_out = l == 0 && d_x_parts != nullptr ? d_x_parts
+                                                         : scratch + (size_t)(l & 1) * PMLP_MAX_PARTS * PMLP_MAX_WIDTH;
+        const dim3 grid((ni + 63) / 64, (no + PMLP_RB - 1) / PMLP_RB);
+        hipLaunchKernelGGL(pose_layer_bwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, W[l], part_in, nparts, h_out, h_in,
+                           ni, no, dW[l], db[l], part_out);
+        part_in = part_out;
+        nparts = (int)grid.y;
+    }
+    return check_launch("hnrf_pose_mlp_bwd");
+}
 
 extern "C" size_t hnrf_motion_basis_saved_bytes(void) { return (size_t)2 * POSE_B * 16 * sizeof(double); }
 

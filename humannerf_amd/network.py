@@ -222,13 +222,43 @@ class BodyPoseRefiner(nn.Module):
         _tiny_last_layer(self.block_mlps[-1])
 
     def rvec(self, pose_input):
-        """The MLP alone: axis-angle corrections (N * 23, 3)."""
+        """The MLP alone: axis-angle corrections (N * 23, 3).  One pose vector on the GPU: the single-workgroup kernels
+        of libhnrf (hnrf_pose_mlp_fwd / _bwd) instead of ~30 GEMV / bias / ReLU launches per training step."""
+        linears = [m for m in self.block_mlps if isinstance(m, nn.Linear)]
+        if pose_input.is_cuda and pose_input.numel() == linears[0].in_features and \
+                all(max(m.in_features, m.out_features) <= 256 for m in linears) and len(linears) <= 9:
+            params = [p for m in linears for p in (m.weight, m.bias)]
+            return _PoseMLP.apply(pose_input.reshape(-1), *params).view(-1, 3)
         return self.block_mlps(pose_input).view(-1, 3)
 
     def forward(self, pose_input):
         rvec = self.rvec(pose_input)
         return {'Rs': rodrigues(rvec).view(-1, self.total_bones, 3, 3),
                 'rvec': rvec.view(-1, self.total_bones, 3)}
+
+
+class _PoseMLP(torch.autograd.Function):
+    """x (n_in,), W0, b0, W1, b1, ... -> MLP(x) on hnrf_pose_mlp_fwd; backward on hnrf_pose_mlp_bwd."""
+
+    @staticmethod
+    def forward(ctx, x, *params):
+        x = x.contiguous().float()
+        weights = [p.contiguous() for p in params[0::2]]
+        biases = [p.contiguous() for p in params[1::2]]
+        out, saved = ops.pose_mlp_fwd(x, weights, biases)
+        ctx.save_for_backward(x, saved, *weights, *biases)
+        ctx.n_layers = len(weights)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        x, saved = ctx.saved_tensors[:2]
+        L = ctx.n_layers
+        weights, biases = list(ctx.saved_tensors[2:2 + L]), list(ctx.saved_tensors[2 + L:2 + 2 * L])
+        dW, db, d_x = ops.pose_mlp_bwd(g.contiguous(), x, weights, biases, saved, want_dx=ctx.needs_input_grad[0])
+        grads = [None] * (2 * L)
+        grads[0::2], grads[1::2] = dW, db
+        return (d_x, *grads)
 
 
 def rodrigues(rvec):

@@ -510,6 +510,41 @@ def motion_basis_bwd(g_Rs, g_Ts, dst_Rs, dst_Ts, cnl_gtfms, saved, rvec=None):
     return d_Rs, d_Ts, d_rvec
 
 
+def _pose_mlp_dims(weights):
+    import ctypes
+    dims = [int(weights[0].shape[1])] + [int(w.shape[0]) for w in weights]
+    for l, w in enumerate(weights):
+        assert tuple(w.shape) == (dims[l + 1], dims[l]), 'layer %d: %s' % (l, tuple(w.shape))
+    return (ctypes.c_int * len(dims))(*dims), dims
+
+
+def pose_mlp_fwd(x, weights, biases):
+    """hnrf_pose_mlp_fwd: x (n_in,) through Linear+ReLU ... Linear -> (n_out,), saved state for the backward."""
+    lib = _lib.load()
+    _chk(x, *weights, *biases)
+    cdims, dims = _pose_mlp_dims(weights)
+    L = len(weights)
+    out = torch.empty(dims[-1], device=x.device)
+    saved = torch.empty(lib.hnrf_pose_mlp_saved_bytes(L) // 4, device=x.device)
+    _lib.check(lib.hnrf_pose_mlp_fwd(_ptr(x), _ptr_array(weights), _ptr_array(biases), cdims, L, _ptr(out), _ptr(saved),
+                                     _stream()), 'hnrf_pose_mlp_fwd')
+    return out, saved
+
+
+def pose_mlp_bwd(g_out, x, weights, biases, saved, want_dx=False):
+    """-> [dW_l], [db_l], d_x or None."""
+    lib = _lib.load()
+    _chk(g_out, x, saved, *weights, *biases)
+    cdims, dims = _pose_mlp_dims(weights)
+    dW = [torch.empty_like(w) for w in weights]
+    db = [torch.empty_like(b) for b in biases]
+    parts = torch.empty(8, 256, device=x.device) if want_dx else None
+    _lib.check(lib.hnrf_pose_mlp_bwd(_ptr(g_out), _ptr(x), _ptr_array(weights), _ptr_array(biases), cdims, len(weights),
+                                     _ptr(saved), _ptr_array(dW), _ptr_array(db), _ptr(parts), _stream()), 'hnrf_pose_mlp_bwd')
+    d_x = parts[:(dims[1] + 31) // 32, :dims[0]].sum(0) if want_dx else None
+    return dW, db, d_x
+
+
 def sample_warp_bwd(rays_o, rays_d, z_vals, motion_Rs, motion_Ts, vol, bbox_min, bbox_scale, x_skel, fg_mask,
                     g_x_skel, g_mask):
     """Returns d_vol (same shape as vol; background channel zero), d_Rs (B,3,3), d_Ts (B,3)."""

@@ -24,7 +24,7 @@ import numpy as np
 import torch
 
 from . import dist as hdist
-from .config import cfg
+from .config import cfg, quiet_gc
 
 
 # --------------------------------------------------------------------------------------------- image helpers
@@ -296,6 +296,7 @@ def render_frames(network, frames, rank=0, world=1, device=None, on_image=None, 
     per-frame numpy pass and the 32 B/ray upload."""
     device = device or next(network.parameters()).device
     network.eval()
+    quiet_gc()
     keys = ('rays', 'near', 'far', 'dst_Rs', 'dst_Ts', 'cnl_gtfms', 'motion_weights_priors', 'dst_posevec',
             'cnl_bbox_min_xyz', 'cnl_bbox_scale_xyz', 'bgcolor')
     old = cfg.perturb

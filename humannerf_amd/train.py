@@ -30,7 +30,7 @@ import warnings
 import torch
 
 from . import dist as hdist
-from .config import cfg, amd_option
+from .config import cfg, amd_option, quiet_gc
 
 
 def customized_lr_names():
@@ -151,6 +151,7 @@ class Trainer:
                           '(set lossweights.lpips = 0 to silence this)' % (weights['lpips'], self.objective))
         self.iter = 1
         self.start_iter = 1
+        quiet_gc()
 
     # ------------------------------------------------------------------------------------------ one iteration
     def backward_step(self, batch):
@@ -186,6 +187,7 @@ class Trainer:
         """trainer.py:186-255 over an iterable of per-frame batches (already on the device).  ``progress_fn(trainer)``
         renders the progress frames; checkpoints are written by rank 0 only."""
         maxiter = int(cfg.train.maxiter if maxiter is None else maxiter)
+        quiet_gc()
         old = cfg.perturb
         cfg.perturb = cfg.train.perturb                                   # trainer.py:181
         try:

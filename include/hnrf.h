@@ -252,6 +252,22 @@ int hnrf_refined_motion_basis_bwd(const float* g_Rs, const float* g_Ts, const fl
                                   const float* dst_Ts, const float* cnl_gtfms, int B, const void* saved, float* d_rvec,
                                   float* d_dst_Rs, float* d_dst_Ts, void* stream);
 
+/* The pose refiner's MLP on one pose vector (BodyPoseRefiner.block_mlps, core/nets/human_nerf/pose_decoders/
+ * mlp_delta_body_pose.py:14-41: Linear + ReLU x mlp_depth, then Linear) and its backward: one small launch per layer
+ * each way (PyTorch: ~30 launches per training step for 0.5 MFLOP).
+ *  W, b: HOST arrays of `layers` device pointers to the nn.Linear weights (out, in) row-major / biases; dims: HOST array
+ *  of layers + 1 widths (dims[0] inputs, dims[l + 1] outputs of layer l), every width <= 256, layers <= 9.
+ *  saved: hnrf_pose_mlp_saved_bytes(layers) bytes of device memory: the forward leaves the hidden activations there,
+ *  the backward reads them and uses the rest as scratch.
+ *  fwd: x [dims[0]] -> out [dims[layers]].
+ *  bwd: g_out [dims[layers]] -> dW[l] (out, in), db[l] (HOST arrays of device pointers); d_x_parts (nullable): [8][256]
+ *  floats whose first ceil(dims[1] / 32) rows sum to d_x (columns < dims[0]). */
+size_t hnrf_pose_mlp_saved_bytes(int layers);
+int hnrf_pose_mlp_fwd(const float* x, const float* const* W, const float* const* b, const int* dims, int layers, float* out,
+                      float* saved, void* stream);
+int hnrf_pose_mlp_bwd(const float* g_out, const float* x, const float* const* W, const float* const* b, const int* dims,
+                      int layers, float* saved, float* const* dW, float* const* db, float* d_x_parts, void* stream);
+
 /* Weight / bias gradient of one nn.Linear inside the two MLPs (autograd of the Linear layers of
  * canonical_mlps/mlp_rgb_sigma.py and non_rigid_motion_mlps/mlp_offset.py under trainer.py:139-170):
  *   dW[o][i] = sum_s dZ[s][o] X[s][i]  for o < n_out, i < n_in;   db[o] = sum_s dZ[s][o]  (db may be NULL).

@@ -35,10 +35,16 @@ def test_network_gradients_match_reference(train_mode, operands, seeded_params, 
       * vs the REFERENCE's own loss.backward() (tests/golden/grad_s64.npz) at the reference's noise floor: its fp32
         gradients are up to 4.4e-3 (norm) away from an fp64 evaluation (tests/test_grad_oracle.py), so 6e-3 / cosine
         0.99998 is what can be asked against it;
-      * vs that fp64 evaluation (torch.autograd through the oracle): norm 1.5e-3 / cosine 0.99999, three times closer
-        than the reference itself gets.  Measured: worst tensor pose_decoder.block_mlps.0.bias 7e-4 / 0.9999954 in BOTH
-        arithmetics (that gradient runs through the fp32 LBS backward and the 4x4 inverses, not through the MLPs) --
-        the split-f16 arithmetic costs nothing measurable on end-to-end gradients; the printed numbers say so."""
+      * vs that fp64 evaluation (torch.autograd through the oracle): 6e-3 / 0.99998 as well (1e-2 / 0.99997 for the pose
+        decoder, which sits behind Rodrigues, the kinematic chain and the 2^9 positional-encoding band).  This problem's
+        gradient is not a smooth function of the forward's last bits: scratch/pose_grad_noise.py evaluates the SAME op
+        sequence (torch GEMVs for the pose MLP, exact-fp32 kernels) twice, the second time with dst_posevec multiplied by
+        1 + 1.2e-7, and the gradients move by 7.8e-3 (pose decoder), 4.5e-3 (canonical MLP, layer 0 bias), 3.2e-3
+        (non-rigid MLP) -- one discrete decision (a ReLU / voxel cell / clamp of one of the 4 096 samples) flips.  Replacing
+        torch's GEMV by hnrf_pose_mlp_fwd (another summation order) flips the same one.  Typical measured values: worst
+        tensor 7e-4 in norm when no such decision flips relative to the fp64 run, 6e-3 when one does; the split-f16
+        arithmetic costs nothing measurable either way (the printed numbers say so).  What pins the kernels' arithmetic
+        tightly are the per-kernel tests below (2e-5 against fp64 autograd of the same MLP / chain / warp)."""
     from humannerf_amd.config import cfg
     from humannerf_amd.network import Network
     from tests.test_grad_oracle import compare_exact
@@ -68,7 +74,7 @@ def test_network_gradients_match_reference(train_mode, operands, seeded_params, 
     grads = {k: (p.grad.cpu().numpy() if p.grad is not None else np.zeros(tuple(p.shape), np.float32))
              for k, p in net.named_parameters()}
     vs_ref = compare_grads(grads, g, rel_norm=6e-3, cos_min=0.99998)
-    vs_exact = compare_exact(grads, exact_gradients, rel_norm=1.5e-3, cos_min=0.99999)
+    vs_exact = compare_exact(grads, exact_gradients, rel_norm=6e-3, cos_min=0.99998, loose=('pose_decoder.', 1e-2, 0.99997))
     print('gradients, training arithmetic', train_mode, 'operands', operands, '| vs reference', vs_ref, '| vs fp64', vs_exact)
 
 
@@ -613,3 +619,47 @@ def test_refined_motion_basis_kernels_match_fp64_autograd():
         with torch.no_grad():
             R3, T3 = motion_basis(T(dst_Rs), T(dst_Ts), T(gt), T(rv))
         assert torch.equal(R3, Rs.detach()) and torch.equal(T3, Ts.detach())
+
+
+def test_pose_mlp_kernels_match_fp64_autograd():
+    """hnrf_pose_mlp_fwd / _bwd (BodyPoseRefiner.block_mlps on one pose vector, one workgroup each way) vs fp64
+    autograd of the same MLP: the default 69-256x4-69, the freshly initialised refiner (last layer at 1e-5), odd shapes."""
+    from humannerf_amd.network import BodyPoseRefiner, _PoseMLP
+    for seed, dims in ((0, [69, 256, 256, 256, 256, 69]), (1, [5, 7, 3]), (2, [69, 128, 69]), (3, [12, 9]),
+                       (4, [256] * 10)):
+        rs = np.random.RandomState(seed)
+        Ws = [(rs.randn(dims[l + 1], dims[l]) / np.sqrt(dims[l])).astype(np.float32) for l in range(len(dims) - 1)]
+        bs = [(rs.randn(dims[l + 1]) * 0.1).astype(np.float32) for l in range(len(dims) - 1)]
+        x = rs.randn(dims[0]).astype(np.float32)
+        g = rs.randn(dims[-1]).astype(np.float32)
+        T = lambda a: torch.from_numpy(a).to(dev())
+        xg = T(x).requires_grad_(True)
+        params = [p for W, b in zip(Ws, bs) for p in (T(W).requires_grad_(True), T(b).requires_grad_(True))]
+        out = _PoseMLP.apply(xg, *params)
+        (out * T(g)).sum().backward()
+        x64 = torch.from_numpy(x).double().requires_grad_(True)
+        p64 = [torch.from_numpy(a).double().requires_grad_(True) for W, b in zip(Ws, bs) for a in (W, b)]
+        h = x64
+        for l in range(len(Ws)):
+            h = p64[2 * l] @ h + p64[2 * l + 1]
+            if l + 1 < len(Ws):
+                h = torch.relu(h)
+        (h * torch.from_numpy(g).double()).sum().backward()
+        assert float((out.detach().double().cpu() - h.detach()).abs().max()) <= 2e-6 * max(1.0, float(h.abs().max()))
+        for got, ref in zip([xg] + params, [x64] + p64):
+            scale = max(float(ref.grad.abs().max()), 1e-30)
+            assert float((got.grad.double().cpu() - ref.grad).abs().max()) <= 5e-6 * scale, (dims, tuple(ref.shape))
+    # the module route: fused rvec == the nn.Sequential it replaces, at the reference's initialisation
+    torch.manual_seed(0)
+    ref = BodyPoseRefiner().to(dev())
+    pose = torch.randn(1, 69, device=dev()) * 0.3
+    a = ref.rvec(pose)
+    b = ref.block_mlps(pose).view(-1, 3)
+    assert a.shape == (23, 3) and float((a - b).abs().max()) <= 1e-9 + 2e-6 * float(b.abs().max())
+    a.square().sum().backward()
+    ga = [p.grad.clone() for p in ref.parameters()]
+    ref.zero_grad()
+    b = ref.block_mlps(pose).view(-1, 3)
+    b.square().sum().backward()
+    for x1, x2 in zip(ga, [p.grad for p in ref.parameters()]):
+        assert float((x1 - x2).abs().max()) <= 1e-5 * max(float(x2.abs().max()), 1e-30)
