@@ -492,8 +492,10 @@ class Network(nn.Module):
         mode = self._mlp_mode()
         nr_packed, cnl_packed, hann_w = None, None, None
         if not ignore_nr:
-            hann_w = hann_window_weights(iter_val, nr_cfg.multires, nr_cfg.kick_in_iter,
-                                         nr_cfg.full_band_iter).to(dev)
+            hann_w = hann_window_weights(iter_val, nr_cfg.multires, nr_cfg.kick_in_iter, nr_cfg.full_band_iter)
+            # through pinned memory: a pageable host-to-device copy waits for everything queued on the stream, i.e. it
+            # would synchronise host and GPU once per training step / frame
+            hann_w = hann_w.pin_memory().to(dev, non_blocking=True) if dev.type == 'cuda' else hann_w.to(dev)
         if not train_path:
             cnl_packed = self._canonical_packed()
             if not ignore_nr:
