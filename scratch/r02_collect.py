@@ -28,7 +28,7 @@ shutil.copy(one('r02_main/*/*_kernel_stats.csv'), os.path.join(P, 'r02_f16x3_ker
 shutil.copy(one('r02_main32/*/*_kernel_stats.csv'), os.path.join(P, 'r02_f32_kernel_stats.csv'))
 shutil.copy(one('r02_train/*/*_kernel_stats.csv'), os.path.join(P, 'r02_train_kernel_stats.csv'))
 for src, dst in (('r02_bench_f16x3.json', 'r02_bench_f16x3.json'), ('r02_bench_f32.json', 'r02_bench_f32.json'),
-                 ('final_bench2.json', 'r02_bench_default.json')):
+                 ('final_bench3.json', 'r02_bench_default.json')):
     line = [l for l in open(os.path.join(G, src)).read().splitlines() if l.startswith('{')][-1]
     open(os.path.join(P, dst), 'w').write(line + '\n')
 
