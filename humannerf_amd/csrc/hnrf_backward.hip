@@ -141,6 +141,12 @@ __global__ void pe_bwd_kernel(const float* __restrict__ x, const float* __restri
 //   dL/dR_b += dL/dpos_b (x) x,   dL/dT_b += dL/dpos_b               (block reduction, 12 atomics)
 // NTH threads per block.  The LDS form (one 128-KiB grid = one block per CU) runs 4 waves per block: with 16 the
 // 8 LDS atomics per (sample, bone) pair contend and the kernel gets 10 % slower (measured 0.90 -> 1.00 ms).
+// lane l <- lane l + N of the same 16-lane row (0 beyond the row)
+template <int N>
+__device__ __forceinline__ int dpp_row_shl(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x100 + N, 0xF, 0xF, true); }
+template <int N>
+__device__ __forceinline__ float dpp_row_shl(float v) { return __int_as_float(dpp_row_shl<N>(__float_as_int(v))); }
+
 template <bool LDS_VOL, int NTH>
 __global__ __launch_bounds__(NTH) void sample_warp_bwd_kernel(
     const float* __restrict__ rays_o, const float* __restrict__ rays_d, const float* __restrict__ z_vals,
@@ -180,8 +186,16 @@ __global__ __launch_bounds__(NTH) void sample_warp_bwd_kernel(
     // arithmetic (P < 2^31 is checked by the launcher).  900 -> ~350 instructions per pair: 0.74 -> 0.44 ms with the
     // atomics idle (all-zero gradient).  With real gradients the 8 ds_add_f32 per pair dominate (0.87 ms): the 64 lanes
     // of a wave are consecutive samples of one ray, ~4.5 of them per voxel, and same-address LDS atomics serialise.
+    // LDS float atomics cost ~3.4 cycles per ACTIVE lane and more when lanes share an address (measured: 0.43 ms of
+    // 0.87; with a quarter of the lanes active they vanish).  The lanes of a wave are consecutive samples of a ray, ~4.5
+    // per voxel cell: runs of lanes in the same cell are folded first (segments inside aligned groups of 8 lanes, three
+    // DPP doubling steps shared by the 8 corners) and only the head of a segment issues the atomic.  Every lane runs
+    // every trip (dead lanes carry zeros) so that the cross-lane reads see defined data.
     const unsigned stride = gridDim.x * NTH;
-    for (unsigned p = blockIdx.x * NTH + threadIdx.x; p < (unsigned)P; p += stride) {
+    const int lane = threadIdx.x & 63;
+    for (unsigned pw = blockIdx.x * NTH + (threadIdx.x & ~63u); pw < (unsigned)P; pw += stride) {
+        const bool live = pw + lane < (unsigned)P;
+        const unsigned p = live ? pw + lane : pw;
         const unsigned r = p / (unsigned)S;
         const float z = z_vals[p];
         const float px = rays_o[r * 3 + 0] + rays_d[r * 3 + 0] * z;
@@ -195,6 +209,7 @@ __global__ __launch_bounds__(NTH) void sample_warp_bwd_kernel(
         const float gA0 = gx0 * inv_den, gA1 = gx1 * inv_den, gA2 = gx2 * inv_den;
         float gws = g_mask[p];
         if (m >= 0.0001f) gws -= (gx0 * xsp[0] + gx1 * xsp[1] + gx2 * xsp[2]) * inv_den;
+        const float alive = live ? 1.f : 0.f;
 
         const float qx = R0 * px + R1 * py + R2 * pz + T0;
         const float qy = R3 * px + R4 * py + R5 * pz + T1;
@@ -221,7 +236,16 @@ __global__ __launch_bounds__(NTH) void sample_warp_bwd_kernel(
         const int yo[2] = {min(max(y0, 0), G - 1) * G, min(max(y0 + 1, 0), G - 1) * G};
         const int zo[2] = {min(max(z0, 0), G - 1) * GG, min(max(z0 + 1, 0), G - 1) * GG};
         float w = 0.f, dwx = 0.f, dwy = 0.f, dwz = 0.f;   // value and d/d(ix,iy,iz)
-        const float dLdw_base = gA0 * qx + gA1 * qy + gA2 * qz + gws;
+        const float dLdw_base = (gA0 * qx + gA1 * qy + gA2 * qz + gws) * alive;
+        // segments: lanes l, l+1, .. of one aligned group of 8 with the same cell (x0, y0, z0 are within [-2, G + 1])
+        const int key = live ? ((z0 + 2) << 22) | ((y0 + 2) << 11) | (x0 + 2) : -1 - lane;
+        const int key_next = dpp_row_shl<1>(key), key_prev = __builtin_amdgcn_update_dpp(0, key, 0x110 + 1, 0xF, 0xF, true);
+        const bool same1 = key_next == key && (lane & 7) < 7;
+        const int s1_next = dpp_row_shl<1>((int)same1);
+        const bool same2 = same1 && s1_next != 0 && (lane & 7) < 6;
+        const int s2_next = dpp_row_shl<2>((int)same2);
+        const bool same4 = same2 && s2_next != 0 && (lane & 7) < 4;
+        const bool head = (lane & 7) == 0 || key_prev != key;
         float v[8];
 #pragma unroll
         for (int c = 0; c < 8; ++c) v[c] = vb[zo[c >> 2] + yo[(c >> 1) & 1] + xc[c & 1]];
@@ -234,17 +258,25 @@ __global__ __launch_bounds__(NTH) void sample_warp_bwd_kernel(
             dwx += v[c] * sxa[ox] * wyz;
             dwy += v[c] * sya[oy] * wxz;
             dwz += v[c] * sza[oz] * wxy;
-            const float contrib = dLdw_base * www;
-            if (contrib != 0.f) {
+            float contrib = dLdw_base * www;
+            // (the cross-lane read first, the select after: inside the conditional only the lanes that take it would
+            // execute the DPP move, and a DPP read from a lane that is masked off returns 0)
+            const float t1 = dpp_row_shl<1>(contrib);
+            contrib += same1 ? t1 : 0.f;
+            const float t2 = dpp_row_shl<2>(contrib);
+            contrib += same2 ? t2 : 0.f;
+            const float t4 = dpp_row_shl<4>(contrib);
+            contrib += same4 ? t4 : 0.f;
+            if (head && contrib != 0.f) {
                 const int idx = zo[oz] + yo[oy] + xc[ox];
                 if (LDS_VOL) atomicAdd(lvol + idx, contrib);
                 else atomicAdd(dvb + idx, contrib);
             }
         }
         // d pos = w gA + dL/dw * grad_pos(w);  d ix / d qx = bsx * 0.5 * (G-1)
-        const float dqx = w * gA0 + dLdw_base * dwx * (bsx * 0.5f * gm1);
-        const float dqy = w * gA1 + dLdw_base * dwy * (bsy * 0.5f * gm1);
-        const float dqz = w * gA2 + dLdw_base * dwz * (bsz * 0.5f * gm1);
+        const float dqx = (w * gA0 + dLdw_base * dwx * (bsx * 0.5f * gm1)) * alive;
+        const float dqy = (w * gA1 + dLdw_base * dwy * (bsy * 0.5f * gm1)) * alive;
+        const float dqz = (w * gA2 + dLdw_base * dwz * (bsz * 0.5f * gm1)) * alive;
         acc[0] += dqx * px; acc[1] += dqx * py; acc[2] += dqx * pz;
         acc[3] += dqy * px; acc[4] += dqy * py; acc[5] += dqy * pz;
         acc[6] += dqz * px; acc[7] += dqz * py; acc[8] += dqz * pz;
