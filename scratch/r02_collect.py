@@ -6,9 +6,9 @@ G, P = os.path.join(R, 'gpurun_out'), os.path.join(R, 'profiles')
 
 
 def one(pattern):
-    f = glob.glob(os.path.join(G, pattern))
-    assert len(f) == 1, (pattern, f)
-    return f[0]
+    f = sorted(glob.glob(os.path.join(G, pattern)), key=os.path.getmtime)      # (older runs stay in gpurun_out/)
+    assert f, pattern
+    return f[-1]
 
 
 def short(name):
