@@ -408,12 +408,13 @@ class DeviceFrameCache:
         bg = (np.random.rand(3) * 255.).astype('float32') if bgcolor is None else np.array(bgcolor, dtype='float32')
         sel, pinfo, div = ent['sampler'].draw(int(cfg.patch.N_patches), int(cfg.patch.size),
                                               subject_ratio=float(cfg.patch.sample_subject_ratio))
-        sel_d = torch.from_numpy(sel.astype(np.int64)).to(dev, non_blocking=True)
-        masks_d = torch.from_numpy(pinfo['mask']).to(dev, non_blocking=True)
-        bg_d = torch.from_numpy(bg).to(dev, non_blocking=True)
+        # uploads through pinned memory: a pageable copy waits for everything queued on the stream (the training
+        # step in flight) and would hold this loader thread for a whole step per tensor
+        up = lambda a: torch.from_numpy(np.ascontiguousarray(a)).pin_memory().to(dev, non_blocking=True)
+        sel_d, masks_d, bg_d = up(sel.astype(np.int64)), up(pinfo['mask']), up(bg)
         # (positions of the kept pixels inside the stacked patches, found on the host: a boolean index on the device
         # would read the count back)
-        flat_d = torch.from_numpy(np.flatnonzero(pinfo['mask'])).to(dev, non_blocking=True)
+        flat_d = up(np.flatnonzero(pinfo['mask']))
         o, d = ent['rays'][0].index_select(0, sel_d), ent['rays'][1].index_select(0, sel_d)
         crops_o = torch.stack([ent['orig'][y0:y1, x0:x1] for (x0, y0), (x1, y1) in zip(pinfo['xy_min'], pinfo['xy_max'])])
         crops_a = torch.stack([ent['alpha'][y0:y1, x0:x1] for (x0, y0), (x1, y1) in zip(pinfo['xy_min'], pinfo['xy_max'])])

@@ -37,7 +37,7 @@ net = Network(); net.load_state_dict({k: torch.from_numpy(v) for k, v in seeded_
 net = net.to(dev)
 for cache in (True, False):
     tr = Trainer(net)
-    stream = dataset.FrameStream(subj, device=dev, device_cache=cache, workers=3, prefetch=4)
+    stream = dataset.FrameStream(subj, device=dev, device_cache=cache, workers=int(os.environ.get("W", 3)), prefetch=int(os.environ.get("PF", 4)))
     cfg.perturb = cfg.train.perturb
     n = iters if cache else max(8, iters // 5)
     for i in range(20 if cache else 4):                      # warm-up: kernels, frame cache (16 frames)
