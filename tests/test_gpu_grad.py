@@ -104,16 +104,19 @@ def test_composite_bwd_kernel():
         assert err <= 2e-5, float(err)
 
 
-@pytest.mark.parametrize('R,G', [(23, 16), (1100, 32)])      # small: global atomics; large: LDS-privatised grid
-def test_sample_warp_bwd_kernel(R, G):
+# small: global atomics; large: LDS-privatised grid; S = 50: a wave's lanes span several rays and the last wave is
+# ragged; span 0.05: a ray stays in one voxel cell for tens of samples (long runs for the atomic fold of K1')
+@pytest.mark.parametrize('R,G,S,span', [(23, 16, 64, 0.5), (1100, 32, 64, 0.5), (37, 32, 50, 0.5), (1400, 32, 50, 0.5),
+                                        (1100, 32, 128, 0.05)])
+def test_sample_warp_bwd_kernel(R, G, S, span):
     from humannerf_amd import ops
     from oracle import oracle
     rs = np.random.RandomState(9)
-    S, B = 64, 24
+    B = 24
     rays_o = rs.uniform(-0.3, 0.3, (R, 3)).astype(np.float32)
     rays_d = rs.uniform(-1, 1, (R, 3)).astype(np.float32)
     near = rs.uniform(0.0, 0.2, (R, 1)).astype(np.float32)
-    far = near + rs.uniform(0.5, 1.0, (R, 1)).astype(np.float32)
+    far = near + rs.uniform(span, 2 * span, (R, 1)).astype(np.float32)
     Rs = (np.eye(3)[None] + 0.1 * rs.randn(B, 3, 3)).astype(np.float32)
     Ts = (0.1 * rs.randn(B, 3)).astype(np.float32)
     vol = rs.uniform(0, 0.1, (B + 1, G, G, G)).astype(np.float32)
