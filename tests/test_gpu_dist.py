@@ -93,8 +93,12 @@ def _worker(rank, world, port, q, mode):
             worst = max(worst, float((ref - p.detach()).abs().max()))
         from humannerf_amd import dist as hd
         merged = hd.gather_frames({k: torch.from_numpy(v) for k, v in imgs.items()}, 5, rank, world)
+        # one frame rendered by both ranks together (ray-range sharding), with the weights of before the step
+        cfg.N_samples, cfg.amd.diagnostics = 32, False
+        split_rgb, _ = render.render_frame_ray_sharded(_net(dev), _cameras()[1], rank, world, device=dev)
+        cfg.N_samples, cfg.amd.diagnostics = S_TRAIN, True
         if rank == 0:
-            q.put((g, nbytes, worst, float(loss), [m.numpy() for m in merged]))
+            q.put((g, nbytes, worst, float(loss), [m.numpy() for m in merged] + [split_rgb]))
         dist.barrier()
     finally:
         dist.destroy_process_group()
@@ -162,7 +166,8 @@ def test_world2_gradients_replicas_and_sharded_render(mode, serial):
     else:
         assert nbytes > dec
     assert worst <= 1e-7, worst                            # replicas stay together after the Adam step
-    assert len(imgs) == 5
+    assert len(imgs) == 6
+    assert np.array_equal(imgs.pop(), want_imgs[1])        # the ray-sharded frame: byte for byte the serial image
     for a, b in zip(imgs, want_imgs):
         assert a.dtype == np.uint8 and a.shape == (96, 96, 3)
         assert np.array_equal(a, b)
