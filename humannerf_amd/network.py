@@ -131,6 +131,9 @@ class _CanonicalParams(nn.Module):
         return [m for m in self.pts_linears if isinstance(m, nn.Linear)] + [self.output_linear[0]]
 
 
+_POINT_CONV = True       # (A/B switch of the 1x1x1 special case, scratch/ab_pose.py)
+
+
 class _ConvT3dK4S2P1(torch.autograd.Function):
     """Forward: the library's transposed convolution.  Backward: two plain GEMMs on the weight's NATIVE layout.
 
@@ -140,15 +143,35 @@ class _ConvT3dK4S2P1(torch.autograd.Function):
         dW[ci, (co,k)] = sum_i      x[i, ci]       col[i, (co,k)]          (Cin x D H W) @ (D H W x 64 Cout)
     -- no permuted copy of the 254 MB of decoder weights.  MIOpen has no tuned backward for these batch-1
     transposed 3-D convolutions: its solver search runs seconds of naive kernels on a fresh machine and settles
-    on anything from 4 to 13 ms per training step for 20 GFLOP of work."""
+    on anything from 4 to 13 ms per training step for 20 GFLOP of work.
+
+    A 1x1x1 input (the decoder's first layer: 1024 -> 512 channels, 33.5 M of the network's 64.4 M parameters) only
+    ever meets the central 2x2x2 taps of the 4x4x4 kernel: out[co, o] = sum_ci x[ci] W[ci, co, o + 1].  That layer
+    is a GEMV on those taps (16.8 MB gathered from the 134 MB tensor) instead of a pass over all 64 taps, forward and
+    backward; the other 56 taps get the zero gradient they always had."""
 
     @staticmethod
     def forward(ctx, x, weight, bias):
+        ctx.point = _POINT_CONV and tuple(x.shape[2:]) == (1, 1, 1)
+        if ctx.point:
+            cin, cout = weight.shape[:2]
+            wc = weight[:, :, 1:3, 1:3, 1:3].reshape(cin, cout * 8)          # (strided gather, contiguous copy)
+            ctx.save_for_backward(x, wc)
+            out = (x.reshape(1, cin) @ wc).reshape(1, cout, 2, 2, 2)
+            return out + bias.reshape(1, cout, 1, 1, 1) if bias is not None else out
         ctx.save_for_backward(x, weight)
         return F.conv_transpose3d(x, weight, bias, stride=2, padding=1)
 
     @staticmethod
     def backward(ctx, g):
+        if ctx.point:
+            x, wc = ctx.saved_tensors
+            cin, cout = wc.shape[0], wc.shape[1] // 8
+            gm = g.reshape(1, cout * 8)
+            dx = (gm @ wc.t()).reshape(1, cin, 1, 1, 1)
+            dw = x.new_zeros(cin, cout, 4, 4, 4)
+            dw[:, :, 1:3, 1:3, 1:3] = (x.reshape(cin, 1) @ gm).reshape(cin, cout, 2, 2, 2)
+            return dx, dw, g[0].sum(dim=(1, 2, 3))
         x, weight = ctx.saved_tensors
         _, cin, D, H, W = x.shape
         cout = weight.shape[1]

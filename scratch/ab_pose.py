@@ -1,4 +1,4 @@
-"""Scratch: A/B of the fused pose-MLP kernels inside the training step (same process, same box)."""
+"""Scratch: A/B of a switch inside the training step (same process, same box); currently the decoder's 1x1x1 layer."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -22,8 +22,8 @@ tr = Trainer(net)
 for _ in range(5):
     tr.train_step(tb)
 for rnd in range(3):
-    for name, f in (('fused', fused), ('torch', torch_route)):
-        N.BodyPoseRefiner.rvec = f
+    for name, f in (('point-conv on', True), ('point-conv off', False)):
+        N._POINT_CONV = f
         for _ in range(3):
             tr.train_step(tb)
         torch.cuda.synchronize(); t0 = time.perf_counter()
