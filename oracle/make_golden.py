@@ -174,7 +174,8 @@ def main():
 
     os.makedirs(GOLD, exist_ok=True)
     for old in os.listdir(GOLD):
-        if old.endswith('.npz') and not old.startswith('patches') and not old.startswith(('image_', 'dataset_')):
+        # (fixtures of the sibling scripts stay: make_golden_patches / _images / _dataset)
+        if old.endswith('.npz') and not old.startswith(('patches', 'image_', 'dataset_', 'subject_')):
             os.remove(os.path.join(GOLD, old))
     # ~260 rays of the 512x512 T-pose framing, per-sample tensors kept for the first 64
     FRAME = dict(H=512, W=512, focal_at_512=1250.0, ray_stride=30, pose_seed=0, bgcolor=(0.0, 0.0, 0.0))
