@@ -61,6 +61,22 @@ def test_abi_argument_errors_do_not_need_a_gpu():
     assert rc == -1 and b'null pointer' in lib.hnrf_last_error()
     rc = lib.hnrf_canonical_fwd(1, 16, 7, 10, 16, None)
     assert rc == -2
+    # every entry point validates before it launches: the round-2 additions
+    import ctypes
+    err = lambda: lib.hnrf_last_error().decode()
+    assert lib.hnrf_motion_basis_fwd(None, None, None, 24, None, None, None, None) == -1 and 'null pointer' in err()
+    assert lib.hnrf_motion_basis_fwd(8, 8, 8, 23, 8, 8, None, None) == -2 and '23 bones' in err()
+    assert lib.hnrf_refined_motion_basis_bwd(8, 8, None, 8, 8, 8, 24, 8, 8, 8, 8, None) == -1
+    dims = (ctypes.c_int * 3)(69, 300, 69)
+    ptrs = (ctypes.c_void_p * 2)(8, 8)
+    assert lib.hnrf_pose_mlp_fwd(8, ptrs, ptrs, dims, 2, 8, 8, None) == -2 and 'width 300' in err()
+    assert lib.hnrf_pose_mlp_fwd(8, ptrs, ptrs, dims, 12, 8, 8, None) == -2 and '12 layers' in err()
+    assert lib.hnrf_pose_mlp_saved_bytes(5) == (4 + 16) * 256 * 4 and lib.hnrf_pose_mlp_saved_bytes(0) == 0
+    assert lib.hnrf_motion_basis_saved_bytes() == 2 * 24 * 16 * 8
+    assert lib.hnrf_mlp_dw_h(None, 0, None, 0, 10, 256, 256, 0, None, None, 0, None, None, 0, None) == -1
+    assert lib.hnrf_mlp_dw_h(8, 256, 8, 256, 10, 200, 256, 0, None, 8, 256, None, 8, 1 << 30, None) == -2 and 'not built' in err()
+    assert lib.hnrf_mlp_dw_h(8, 256, 8, 256, 10, 256, 256, 4, None, 8, 256, None, 8, 1 << 30, None) == -1 and 'bad layout' in err()
+    assert lib.hnrf_mlp_dw_h_workspace_bytes(786432, 256, 256) > 0 and lib.hnrf_mlp_dw_h_workspace_bytes(10, 200, 256) == 0
 
 
 def test_hot_path_fails_loudly_without_gpu():
