@@ -1096,19 +1096,16 @@ __global__ __launch_bounds__(256) void nonrigid_f16x3_x2_kernel(const float* __r
     float last[2][16];
     constexpr int MID = NR16_NB_MID, L4B = NR16_NB_L4;          // blocks per tile: 16 / 24
     layer16x2<4, 2, 4, 0, true>(p, SPW, MID, MID, hB_h, hB_l, hA_h, hA_l, last);            // L0 (hB unused: NKB = 0)
-#pragma unroll 1
-    for (int l = 1; l <= 3; ++l) {
-        const int nb = l == 3 ? L4B : MID;
-        layer16x2<4, 1, 0, 8, true>(p, SPW, nb, nb, hA_h, hA_l, hB_h, hB_l, last);
-#pragma unroll
-        for (int g = 0; g < 2; ++g)
-#pragma unroll
-            for (int i = 0; i < 8; ++i) { hA_h[g][i] = hB_h[g][i]; hA_l[g][i] = hB_l[g][i]; }
-    }
-    layer16x2<4, 1, 4, 8, true>(p, SPW, MID, MID, hA_h, hA_l, hB_h, hB_l, last);             // skip layer
-    layer16x2<4, 1, 0, 8, true>(p, SPW, MID, 0, hB_h, hB_l, hA_h, hA_l, last);
+    // the layers alternate between the two fragment arrays: a loop over the three equal mid layers would have to copy
+    // its output back into its input array, 128 registers per layer and group pair, most of them AGPR <-> VGPR moves --
+    // a third of the kernel's non-MFMA instructions, and this kernel's time follows its instruction count
+    layer16x2<4, 1, 0, 8, true>(p, SPW, MID, MID, hA_h, hA_l, hB_h, hB_l, last);             // L1
+    layer16x2<4, 1, 0, 8, true>(p, SPW, MID, MID, hB_h, hB_l, hA_h, hA_l, last);             // L2
+    layer16x2<4, 1, 0, 8, true>(p, SPW, L4B, L4B, hA_h, hA_l, hB_h, hB_l, last);             // L3
+    layer16x2<4, 1, 4, 8, true>(p, SPW, MID, MID, hB_h, hB_l, hA_h, hA_l, last);             // skip layer
+    layer16x2<4, 1, 0, 8, true>(p, SPW, MID, 0, hA_h, hA_l, hB_h, hB_l, last);
     h16x8 dh[2][2], dl[2][2];
-    layer16x2<1, 1, 0, 8, false>(p, SPW, 0, 0, hA_h, hA_l, dh, dl, last);
+    layer16x2<1, 1, 0, 8, false>(p, SPW, 0, 0, hB_h, hB_l, dh, dl, last);
     const float* ob = reinterpret_cast<const float*>(packed + NR16_BIAS + NR16_BIAS_LDS);
     const float hs = ob[8];
 #pragma unroll
