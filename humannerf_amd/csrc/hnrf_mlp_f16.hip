@@ -1007,20 +1007,19 @@ __global__ __launch_bounds__(256) void nonrigid_f16x3_kernel(const float* __rest
     float last[16];
     layer16<4, 4, 4, 0, true, SAVE>(p, 0 /*already in flight*/, 2 * NR16_NB_MID, hB_h, hB_l, hA_h, hA_l, last, &sc);
     if constexpr (SAVE) { sc.row += act_stride; sc.rowh += acth_stride; sc.bits += bit_stride; }
-#pragma unroll 1
-    for (int l = 1; l <= 3; ++l) {
-        // 128-wide tiles have only 8 k-steps: two tiles per slab halve the barriers per MFMA
-        const int nb = l == 3 ? NR16_NB_L4 : 2 * NR16_NB_MID;
-        layer16<4, 2, 0, 8, true, SAVE>(p, nb, nb, hA_h, hA_l, hB_h, hB_l, last, &sc);
-        if constexpr (SAVE) { sc.row += act_stride; sc.rowh += acth_stride; sc.bits += bit_stride; }
-#pragma unroll
-        for (int i = 0; i < 8; ++i) { hA_h[i] = hB_h[i]; hA_l[i] = hB_l[i]; }
-    }
-    layer16<4, 1, 4, 8, true, SAVE>(p, 2 * NR16_NB_MID, 2 * NR16_NB_MID, hA_h, hA_l, hB_h, hB_l, last, &sc);    // skip layer
+    // 128-wide tiles have only 8 k-steps: two tiles per slab halve the barriers per MFMA.  The layers alternate
+    // between the two fragment arrays (no loop with a copy-back: this kernel's time follows its instruction count)
+    layer16<4, 2, 0, 8, true, SAVE>(p, 2 * NR16_NB_MID, 2 * NR16_NB_MID, hA_h, hA_l, hB_h, hB_l, last, &sc);     // L1
     if constexpr (SAVE) { sc.row += act_stride; sc.rowh += acth_stride; sc.bits += bit_stride; }
-    layer16<4, 2, 0, 8, true, SAVE>(p, NR16_NB_MID, 0, hB_h, hB_l, hA_h, hA_l, last, &sc);
+    layer16<4, 2, 0, 8, true, SAVE>(p, 2 * NR16_NB_MID, 2 * NR16_NB_MID, hB_h, hB_l, hA_h, hA_l, last, &sc);     // L2
+    if constexpr (SAVE) { sc.row += act_stride; sc.rowh += acth_stride; sc.bits += bit_stride; }
+    layer16<4, 2, 0, 8, true, SAVE>(p, NR16_NB_L4, NR16_NB_L4, hA_h, hA_l, hB_h, hB_l, last, &sc);               // L3
+    if constexpr (SAVE) { sc.row += act_stride; sc.rowh += acth_stride; sc.bits += bit_stride; }
+    layer16<4, 1, 4, 8, true, SAVE>(p, 2 * NR16_NB_MID, 2 * NR16_NB_MID, hB_h, hB_l, hA_h, hA_l, last, &sc);    // skip layer
+    if constexpr (SAVE) { sc.row += act_stride; sc.rowh += acth_stride; sc.bits += bit_stride; }
+    layer16<4, 2, 0, 8, true, SAVE>(p, NR16_NB_MID, 0, hA_h, hA_l, hB_h, hB_l, last, &sc);
     h16x8 dh[2], dl[2];
-    layer16<1, 1, 0, 8, false>(p, 0, 0, hA_h, hA_l, dh, dl, last);
+    layer16<1, 1, 0, 8, false>(p, 0, 0, hB_h, hB_l, dh, dl, last);
     const float* ob = reinterpret_cast<const float*>(packed + NR16_BIAS + NR16_BIAS_LDS);
     const float hs = ob[8];                                     // head descale (pack_layer16_kernel, head_scale)
     if (h == 0 && slot < P) {
@@ -1437,14 +1436,12 @@ __global__ __launch_bounds__(256) void nonrigid_bwd16_kernel(const float* __rest
     float dpe[18];
 #pragma unroll
     for (int j = 0; j < 18; ++j) dpe[j] = sc.fout[j] * inv_skip;
-#pragma unroll 1
-    for (int m = 2; m >= 1; --m) {                                                            // dZ2, dZ1
-        load_mask();
-        layer16<4, 2, 0, 8, false, SV>(p, 32, 32, hA_h, hA_l, hB_h, hB_l, last, &sc);
-        next_stage(m);
-#pragma unroll
-        for (int i = 0; i < 8; ++i) { hA_h[i] = hB_h[i]; hA_l[i] = hB_l[i]; }
-    }
+    load_mask();
+    layer16<4, 2, 0, 8, false, SV>(p, 32, 32, hA_h, hA_l, hB_h, hB_l, last, &sc);             // dZ2
+    next_stage(2);
+    load_mask();
+    layer16<4, 2, 0, 8, false, SV>(p, 32, 32, hB_h, hB_l, hA_h, hA_l, last, &sc);             // dZ1
+    next_stage(1);
     load_mask();
     layer16<4, 2, 0, 8, false, SV>(p, 32, 0, hA_h, hA_l, hB_h, hB_l, last, &sc);              // dZ0
     next_stage(0);                                                                             // (scale of layer 0's d PE)
