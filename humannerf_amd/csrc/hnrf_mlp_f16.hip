@@ -292,6 +292,42 @@ __device__ __forceinline__ void epi_pair(const f32x16& a1, const f32x16& a2, int
     lo[e + 1] = ll[1];
 }
 
+// Un-scaled low part (two-group K2 kernel): lo = f16(x - hi) without the 2^11 lift, one VALU less per value.  lo then
+// drops into f16 subnormals for |x| < 2^-3 and x is represented to max(2^-25, 2^-22 |x|) instead of 2^-22 |x|: an
+// ABSOLUTE floor of 3e-8 on activations of order 0.1 .. 1 -- what a dot product over them sees is the same.  The
+// products wh . xl then carry no 2^11 and go into the FIRST accumulator; wl keeps its lift (weights are packed
+// offline and 2^-12 |w| would sit far down in the subnormals).
+template <bool RELU>
+__device__ __forceinline__ void epi_pair_u(const f32x16& a1, const f32x16& a2, int i, h16x8& hi, h16x8& lo) {
+    float x0 = fmaf(a2[2 * i], LO_INV, a1[2 * i]);
+    float x1 = fmaf(a2[2 * i + 1], LO_INV, a1[2 * i + 1]);
+    if (RELU) {
+        x0 = __builtin_amdgcn_fmed3f(x0, 0.f, 65504.f);
+        x1 = __builtin_amdgcn_fmed3f(x1, 0.f, 65504.f);
+    }
+    const h16x2 hh = __builtin_convertvector(f32x2{x0, x1}, h16x2);
+    const float r0 = fmaf((float)hh[0], -1.0f, x0);               // v_fma_mix_f32
+    const float r1 = fmaf((float)hh[1], -1.0f, x1);
+    const h16x2 ll = __builtin_convertvector(f32x2{r0, r1}, h16x2);
+    const int e = 2 * (i & 3);
+    hi[e] = hh[0];
+    hi[e + 1] = hh[1];
+    lo[e] = ll[0];
+    lo[e + 1] = ll[1];
+}
+__device__ __forceinline__ void split8_u(const float (&v)[8], h16x8& hi, h16x8& lo) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const f32x2 p = {v[2 * i], v[2 * i + 1]};
+        const h16x2 hh = __builtin_convertvector(p, h16x2);
+        const h16x2 ll = __builtin_convertvector(f32x2{p[0] - (float)hh[0], p[1] - (float)hh[1]}, h16x2);
+        hi[2 * i] = hh[0];
+        hi[2 * i + 1] = hh[1];
+        lo[2 * i] = ll[0];
+        lo[2 * i + 1] = ll[1];
+    }
+}
+
 // epi_pair that also hands back the two activations (training variant stores them)
 template <bool RELU>
 __device__ __forceinline__ h16x2 epi_pair_x(const f32x16& a1, const f32x16& a2, int i, h16x8& hi, h16x8& lo, float& x0o,
@@ -760,7 +796,7 @@ __device__ __forceinline__ void layer16x2(Pipe& p, unsigned stash_per_wave, int 
 #pragma unroll
                 for (int g = 0; g < 2; ++g) {
                     acc1[g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, xh[g], acc1[g], 0, 0, 0);
-                    acc2[g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, xl[g], acc2[g], 0, 0, 0);
+                    acc1[g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, xl[g], acc1[g], 0, 0, 0);     // (xl un-scaled: epi_pair_u)
                     acc2[g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, xh[g], acc2[g], 0, 0, 0);
                 }
                 {
@@ -779,7 +815,7 @@ __device__ __forceinline__ void layer16x2(Pipe& p, unsigned stash_per_wave, int 
                     for (int j = 0; j < 16; ++j)
                         if ((j * NK) / 16 == ks) {
                             const int g = j >> 3, i = j & 7;
-                            epi_pair<RELU>(pacc1[g], pacc2[g], i, oh[g][2 * (t - 1) + (i >> 2)], ol[g][2 * (t - 1) + (i >> 2)]);
+                            epi_pair_u<RELU>(pacc1[g], pacc2[g], i, oh[g][2 * (t - 1) + (i >> 2)], ol[g][2 * (t - 1) + (i >> 2)]);
                             asm volatile("" : "+v"(oh[g][2 * (t - 1) + (i >> 2)]), "+v"(ol[g][2 * (t - 1) + (i >> 2)]));
                         }
                 }
@@ -815,7 +851,7 @@ __device__ __forceinline__ void layer16x2(Pipe& p, unsigned stash_per_wave, int 
         } else {
 #pragma unroll
             for (int i = 0; i < 8; ++i)
-                epi_pair<RELU>(pacc1[g], pacc2[g], i, oh[g][2 * (NT - 1) + (i >> 2)], ol[g][2 * (NT - 1) + (i >> 2)]);
+                epi_pair_u<RELU>(pacc1[g], pacc2[g], i, oh[g][2 * (NT - 1) + (i >> 2)], ol[g][2 * (NT - 1) + (i >> 2)]);
         }
     }
 }
@@ -1084,7 +1120,7 @@ __global__ __launch_bounds__(256) void nonrigid_f16x3_x2_kernel(const float* __r
             const float v[8] = {pev[8 * ks], pev[8 * ks + 1], pev[8 * ks + 2], pev[8 * ks + 3],
                                 pev[8 * ks + 4], pev[8 * ks + 5], pev[8 * ks + 6], pev[8 * ks + 7]};
             h16x8 hi, lo;
-            split8(v, hi, lo);
+            split8_u(v, hi, lo);
             lds_st8(pe + (2 * ks) * 1024, hi);
             lds_st8(pe + (2 * ks + 1) * 1024, lo);
         }
