@@ -487,7 +487,7 @@ __device__ __forceinline__ h16x2 epi_pair_mh(const f32x16& a1, const f32x16& a2,
 //     behind; with DEFER it is left pending in (pend1, pend2) and the next layer (PEND_IN) runs it inside its first
 //     tile, writing the last two fragments of its own input just before the k-steps that consume them.
 template <int NT, int TPS, int NKA, int NKB, bool RELU, int SAVE = 0, bool PEND_IN = false, bool DEFER = false,
-          int NB, int NO>
+          bool ULO = false, int NB, int NO>
 __device__ __forceinline__ void layer16(Pipe& p, int nb1, int nb2, h16x8 (&bh)[NB], h16x8 (&bl)[NB],
                                         h16x8 (&oh)[NO], h16x8 (&ol)[NO], float (&last)[16], SaveCtx* sc = nullptr,
                                         f32x16* pend1 = nullptr, f32x16* pend2 = nullptr) {
@@ -499,6 +499,7 @@ __device__ __forceinline__ void layer16(Pipe& p, int nb1, int nb2, h16x8 (&bh)[N
     constexpr int NS = NT / TPS;             // slabs of this layer
     constexpr int PFK = NK < 4 ? NK : 4;
     static_assert((NBLK * TPS) % 4 == 0, "every wave must issue the same number of DMA pieces per slab");
+    static_assert(!ULO || SAVE == SV_NONE, "un-scaled activation low parts (epi_pair_u) exist in the inference form only");
     f32x16 pacc1 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     f32x16 pacc2 = pacc1;                    // accumulators of the previous tile (epilogue pending)
     f32x16 nbias = pacc1;                    // bias of the NEXT tile: the table is resident in LDS, so it is read
@@ -581,7 +582,8 @@ __device__ __forceinline__ void layer16(Pipe& p, int nb1, int nb2, h16x8 (&bh)[N
                     }
                 }
                 acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, xh, acc1, 0, 0, 0);
-                acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, xl, acc2, 0, 0, 0);
+                if (ULO) acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, xl, acc1, 0, 0, 0);
+                else acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, xl, acc2, 0, 0, 0);
                 acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, xh, acc2, 0, 0, 0);
                 if (NT > 1 && sv_has_bias(SAVE) && ks == NK - 1 && t + 1 < NT) {
                     const unsigned bn = p.lds_base + p.bias_off + (tt + 1) * 128 + (lane >> 5) * 16;   // (tt + 1 == TPS: next slab's first)
@@ -606,7 +608,7 @@ __device__ __forceinline__ void layer16(Pipe& p, int nb1, int nb2, h16x8 (&bh)[N
 #pragma unroll
                     for (int i = 0; i < 8; ++i)
                         if ((i * (NK - 1)) / 8 == ks) {
-                            epi_pair<true>(*pend1, *pend2, i, bh[NKB - 2 + (i >> 2)], bl[NKB - 2 + (i >> 2)]);
+                            epi_pair_u<true>(*pend1, *pend2, i, bh[NKB - 2 + (i >> 2)], bl[NKB - 2 + (i >> 2)]);
                             asm volatile("" : "+v"(bh[NKB - 2 + (i >> 2)]), "+v"(bl[NKB - 2 + (i >> 2)]));
                         }
                 }
@@ -638,7 +640,7 @@ __device__ __forceinline__ void layer16(Pipe& p, int nb1, int nb2, h16x8 (&bh)[N
                                 sc->fout[16 * (t - 1) + 2 * i] = fmaf(pacc2[2 * i], LO_INV, pacc1[2 * i]);
                                 sc->fout[16 * (t - 1) + 2 * i + 1] = fmaf(pacc2[2 * i + 1], LO_INV, pacc1[2 * i + 1]);
                             } else
-                            epi_pair<RELU>(pacc1, pacc2, i, oh[2 * (t - 1) + (i >> 2)], ol[2 * (t - 1) + (i >> 2)]);
+                            epi_pair_u<RELU>(pacc1, pacc2, i, oh[2 * (t - 1) + (i >> 2)], ol[2 * (t - 1) + (i >> 2)]);
                             // pin the result here: without a use in this block hipcc sinks the whole
                             // epilogue to the first consumer (the next layer), out of the MFMA shadow
                             if constexpr (SAVE != SV_PE)
@@ -703,7 +705,7 @@ __device__ __forceinline__ void layer16(Pipe& p, int nb1, int nb2, h16x8 (&bh)[N
                 sc->fout[16 * (NT - 1) + 2 * i] = fmaf(pacc2[2 * i], LO_INV, pacc1[2 * i]);
                 sc->fout[16 * (NT - 1) + 2 * i + 1] = fmaf(pacc2[2 * i + 1], LO_INV, pacc1[2 * i + 1]);
             } else
-            epi_pair<RELU>(pacc1, pacc2, i, oh[2 * (NT - 1) + (i >> 2)], ol[2 * (NT - 1) + (i >> 2)]);
+            epi_pair_u<RELU>(pacc1, pacc2, i, oh[2 * (NT - 1) + (i >> 2)], ol[2 * (NT - 1) + (i >> 2)]);
         }
         if constexpr (sv_fwd(SAVE)) {
 #pragma unroll
@@ -878,9 +880,11 @@ __device__ __forceinline__ Pipe pipe_start(const char* packed, int64_t bias_img_
     return p;
 }
 
+template <bool ULO = false>
 __device__ __forceinline__ void stash_pe(const Pipe& p, int ks, const float (&v)[8]) {
     h16x8 hi, lo;
-    split8(v, hi, lo);
+    if (ULO) split8_u(v, hi, lo);
+    else split8(v, hi, lo);
     const unsigned pe = p.lds_base + p.pe_off + p.wave * (PE_STASH / 4) + lane_now() * 16;
     lds_st8(pe + (2 * ks) * 1024, hi);
     lds_st8(pe + (2 * ks + 1) * 1024, lo);
@@ -897,6 +901,7 @@ __global__ __launch_bounds__(256) void canonical_f16x3_kernel(const float* __res
                                                               const int* __restrict__ count,
                                                               float* __restrict__ pe_out, float* __restrict__ acts,
                                                               uint32_t* __restrict__ relu_bits) {
+    constexpr bool UL = SAVE == SV_NONE;                        // un-scaled activation low parts (epi_pair_u)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // sparse launch: only the `*count` samples listed in idx are evaluated (hnrf_compact_samples)
     if (idx != nullptr) {
@@ -920,7 +925,7 @@ __global__ __launch_bounds__(256) void canonical_f16x3_kernel(const float* __res
     for (int ks = 0; ks < 4; ++ks) {
         const float v[8] = {pev[8 * ks], pev[8 * ks + 1], pev[8 * ks + 2], pev[8 * ks + 3],
                             pev[8 * ks + 4], pev[8 * ks + 5], pev[8 * ks + 6], pev[8 * ks + 7]};
-        stash_pe(p, ks, v);
+        stash_pe<UL>(p, ks, v);
     }
     SaveCtx sc;
     if constexpr (SAVE) {
@@ -945,29 +950,29 @@ __global__ __launch_bounds__(256) void canonical_f16x3_kernel(const float* __res
     float last[16];
     f32x16 pend1, pend2;                          // inference: last-tile epilogues travel into the next layer
     constexpr bool DF = SAVE == SV_NONE;
-    layer16<8, 4, 4, 0, true, SAVE, false, DF>(p, CNL16_NB_MID, CNL16_NB_MID, hB_h, hB_l, hA_h, hA_l, last, &sc, &pend1, &pend2);   // (hB unused: NKB = 0)
+    layer16<8, 4, 4, 0, true, SAVE, false, DF, UL>(p, CNL16_NB_MID, CNL16_NB_MID, hB_h, hB_l, hA_h, hA_l, last, &sc, &pend1, &pend2);   // (hB unused: NKB = 0)
     if constexpr (SAVE) { sc.row += act_stride; sc.rowh += acth_stride; sc.bits += bit_stride; }
 #pragma unroll 1
     for (int l = 1; l <= 4; ++l) {
         const int nb = l == 4 ? CNL16_NB_L5 : CNL16_NB_MID;
-        layer16<8, 1, 0, 16, true, SAVE, DF, DF>(p, nb, nb, hA_h, hA_l, hB_h, hB_l, last, &sc, &pend1, &pend2);
+        layer16<8, 1, 0, 16, true, SAVE, DF, DF, UL>(p, nb, nb, hA_h, hA_l, hB_h, hB_l, last, &sc, &pend1, &pend2);
         if constexpr (SAVE) { sc.row += act_stride; sc.rowh += acth_stride; sc.bits += bit_stride; }
 #pragma unroll
         for (int i = 0; i < 16; ++i) { hA_h[i] = hB_h[i]; hA_l[i] = hB_l[i]; }
     }
-    layer16<8, 1, 4, 16, true, SAVE, DF, DF>(p, CNL16_NB_MID, CNL16_NB_MID, hA_h, hA_l, hB_h, hB_l, last, &sc, &pend1, &pend2);   // skip layer
+    layer16<8, 1, 4, 16, true, SAVE, DF, DF, UL>(p, CNL16_NB_MID, CNL16_NB_MID, hA_h, hA_l, hB_h, hB_l, last, &sc, &pend1, &pend2);   // skip layer
     if constexpr (SAVE) { sc.row += act_stride; sc.rowh += acth_stride; sc.bits += bit_stride; }
 #pragma unroll
     for (int i = 0; i < 16; ++i) { hA_h[i] = hB_h[i]; hA_l[i] = hB_l[i]; }
 #pragma unroll 1
     for (int l = 6; l <= 7; ++l) {
-        layer16<8, 1, 0, 16, true, SAVE, DF, DF>(p, CNL16_NB_MID, l == 7 ? 0 : CNL16_NB_MID, hA_h, hA_l, hB_h, hB_l, last, &sc, &pend1, &pend2);
+        layer16<8, 1, 0, 16, true, SAVE, DF, DF, UL>(p, CNL16_NB_MID, l == 7 ? 0 : CNL16_NB_MID, hA_h, hA_l, hB_h, hB_l, last, &sc, &pend1, &pend2);
         if constexpr (SAVE) { sc.row += act_stride; sc.rowh += acth_stride; sc.bits += bit_stride; }
 #pragma unroll
         for (int i = 0; i < 16; ++i) { hA_h[i] = hB_h[i]; hA_l[i] = hB_l[i]; }
     }
     h16x8 dh[2], dl[2];
-    layer16<1, 1, 0, 16, false, 0, DF, false>(p, 0, 0, hA_h, hA_l, dh, dl, last, nullptr, &pend1, &pend2);
+    layer16<1, 1, 0, 16, false, 0, DF, false, UL>(p, 0, 0, hA_h, hA_l, dh, dl, last, nullptr, &pend1, &pend2);
     // head bias and the head's power-of-two descale (pack_layer16_kernel, head_scale): scalar loads
     const float* ob = reinterpret_cast<const float*>(packed + CNL16_BIAS + CNL16_BIAS_LDS);
     const float hs = ob[8];
@@ -993,6 +998,7 @@ __global__ __launch_bounds__(256) void nonrigid_f16x3_kernel(const float* __rest
                                                              const int* __restrict__ count,
                                                              float* __restrict__ pe_out, float* __restrict__ acts,
                                                              uint32_t* __restrict__ relu_bits) {
+    constexpr bool UL = SAVE == SV_NONE;                        // un-scaled activation low parts (epi_pair_u)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     if (idx != nullptr) {
         P = *count;
@@ -1016,7 +1022,7 @@ __global__ __launch_bounds__(256) void nonrigid_f16x3_kernel(const float* __rest
     for (int ks = 0; ks < 4; ++ks) {
         const float v[8] = {pev[8 * ks], pev[8 * ks + 1], pev[8 * ks + 2], pev[8 * ks + 3],
                             pev[8 * ks + 4], pev[8 * ks + 5], pev[8 * ks + 6], pev[8 * ks + 7]};
-        stash_pe(p, ks, v);
+        stash_pe<UL>(p, ks, v);
     }
     SaveCtx sc;
     if constexpr (SAVE) {
@@ -1041,21 +1047,21 @@ __global__ __launch_bounds__(256) void nonrigid_f16x3_kernel(const float* __rest
 
     h16x8 hA_h[8], hA_l[8], hB_h[8], hB_l[8];
     float last[16];
-    layer16<4, 4, 4, 0, true, SAVE>(p, 0 /*already in flight*/, 2 * NR16_NB_MID, hB_h, hB_l, hA_h, hA_l, last, &sc);
+    layer16<4, 4, 4, 0, true, SAVE, false, false, UL>(p, 0 /*already in flight*/, 2 * NR16_NB_MID, hB_h, hB_l, hA_h, hA_l, last, &sc);
     if constexpr (SAVE) { sc.row += act_stride; sc.rowh += acth_stride; sc.bits += bit_stride; }
     // 128-wide tiles have only 8 k-steps: two tiles per slab halve the barriers per MFMA.  The layers alternate
     // between the two fragment arrays (no loop with a copy-back: this kernel's time follows its instruction count)
-    layer16<4, 2, 0, 8, true, SAVE>(p, 2 * NR16_NB_MID, 2 * NR16_NB_MID, hA_h, hA_l, hB_h, hB_l, last, &sc);     // L1
+    layer16<4, 2, 0, 8, true, SAVE, false, false, UL>(p, 2 * NR16_NB_MID, 2 * NR16_NB_MID, hA_h, hA_l, hB_h, hB_l, last, &sc);     // L1
     if constexpr (SAVE) { sc.row += act_stride; sc.rowh += acth_stride; sc.bits += bit_stride; }
-    layer16<4, 2, 0, 8, true, SAVE>(p, 2 * NR16_NB_MID, 2 * NR16_NB_MID, hB_h, hB_l, hA_h, hA_l, last, &sc);     // L2
+    layer16<4, 2, 0, 8, true, SAVE, false, false, UL>(p, 2 * NR16_NB_MID, 2 * NR16_NB_MID, hB_h, hB_l, hA_h, hA_l, last, &sc);     // L2
     if constexpr (SAVE) { sc.row += act_stride; sc.rowh += acth_stride; sc.bits += bit_stride; }
-    layer16<4, 2, 0, 8, true, SAVE>(p, NR16_NB_L4, NR16_NB_L4, hA_h, hA_l, hB_h, hB_l, last, &sc);               // L3
+    layer16<4, 2, 0, 8, true, SAVE, false, false, UL>(p, NR16_NB_L4, NR16_NB_L4, hA_h, hA_l, hB_h, hB_l, last, &sc);               // L3
     if constexpr (SAVE) { sc.row += act_stride; sc.rowh += acth_stride; sc.bits += bit_stride; }
-    layer16<4, 1, 4, 8, true, SAVE>(p, 2 * NR16_NB_MID, 2 * NR16_NB_MID, hB_h, hB_l, hA_h, hA_l, last, &sc);    // skip layer
+    layer16<4, 1, 4, 8, true, SAVE, false, false, UL>(p, 2 * NR16_NB_MID, 2 * NR16_NB_MID, hB_h, hB_l, hA_h, hA_l, last, &sc);    // skip layer
     if constexpr (SAVE) { sc.row += act_stride; sc.rowh += acth_stride; sc.bits += bit_stride; }
-    layer16<4, 2, 0, 8, true, SAVE>(p, NR16_NB_MID, 0, hA_h, hA_l, hB_h, hB_l, last, &sc);
+    layer16<4, 2, 0, 8, true, SAVE, false, false, UL>(p, NR16_NB_MID, 0, hA_h, hA_l, hB_h, hB_l, last, &sc);
     h16x8 dh[2], dl[2];
-    layer16<1, 1, 0, 8, false>(p, 0, 0, hB_h, hB_l, dh, dl, last);
+    layer16<1, 1, 0, 8, false, 0, false, false, UL>(p, 0, 0, hB_h, hB_l, dh, dl, last);
     const float* ob = reinterpret_cast<const float*>(packed + NR16_BIAS + NR16_BIAS_LDS);
     const float hs = ob[8];                                     // head descale (pack_layer16_kernel, head_scale)
     if (h == 0 && slot < P) {
