@@ -306,8 +306,12 @@ __device__ __forceinline__ void epi_pair_u(const f32x16& a1, const f32x16& a2, i
         x1 = __builtin_amdgcn_fmed3f(x1, 0.f, 65504.f);
     }
     const h16x2 hh = __builtin_convertvector(f32x2{x0, x1}, h16x2);
-    const float r0 = fmaf((float)hh[0], -1.0f, x0);               // v_fma_mix_f32
-    const float r1 = fmaf((float)hh[1], -1.0f, x1);
+    // x - hi in ONE v_fma_mix_f32 (f16 operand converted inside): with a literal -1 hipcc rewrites the fma as
+    // v_cvt_f32_f16 + v_sub_f32, so the factor is made opaque
+    float m1 = -1.0f;
+    asm("" : "+v"(m1));
+    const float r0 = fmaf((float)hh[0], m1, x0);
+    const float r1 = fmaf((float)hh[1], m1, x1);
     const h16x2 ll = __builtin_convertvector(f32x2{r0, r1}, h16x2);
     const int e = 2 * (i & 3);
     hi[e] = hh[0];
