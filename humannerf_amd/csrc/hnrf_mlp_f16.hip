@@ -333,7 +333,7 @@ __device__ __forceinline__ void split8_u(const float (&v)[8], h16x8& hi, h16x8& 
 }
 
 // epi_pair that also hands back the two activations (training variant stores them)
-template <bool RELU>
+template <bool RELU, bool ULO = false>
 __device__ __forceinline__ h16x2 epi_pair_x(const f32x16& a1, const f32x16& a2, int i, h16x8& hi, h16x8& lo, float& x0o,
                                             float& x1o) {
     float x0 = fmaf(a2[2 * i], LO_INV, a1[2 * i]);
@@ -343,9 +343,16 @@ __device__ __forceinline__ h16x2 epi_pair_x(const f32x16& a1, const f32x16& a2, 
         x1 = __builtin_amdgcn_fmed3f(x1, 0.f, 65504.f);
     }
     const h16x2 hh = __builtin_convertvector(f32x2{x0, x1}, h16x2);
-    // (x - hi) * 2^11, exact; written so that hipcc folds the f16 -> f32 conversion into v_fma_mix_f32
-    const float r0 = fmaf((float)hh[0], -LO_SCALE, x0 * LO_SCALE);
-    const float r1 = fmaf((float)hh[1], -LO_SCALE, x1 * LO_SCALE);
+    float r0, r1;
+    if (ULO) {                  // un-scaled low part, see epi_pair_u
+        float m1 = -1.0f;
+        asm("" : "+v"(m1));
+        r0 = fmaf((float)hh[0], m1, x0);
+        r1 = fmaf((float)hh[1], m1, x1);
+    } else {                    // (x - hi) * 2^11, exact; written so that hipcc folds the f16 -> f32 conversion into v_fma_mix_f32
+        r0 = fmaf((float)hh[0], -LO_SCALE, x0 * LO_SCALE);
+        r1 = fmaf((float)hh[1], -LO_SCALE, x1 * LO_SCALE);
+    }
     const h16x2 ll = __builtin_convertvector(f32x2{r0, r1}, h16x2);
     const int e = 2 * (i & 3);
     hi[e] = hh[0];
@@ -503,7 +510,7 @@ __device__ __forceinline__ void layer16(Pipe& p, int nb1, int nb2, h16x8 (&bh)[N
     constexpr int NS = NT / TPS;             // slabs of this layer
     constexpr int PFK = NK < 4 ? NK : 4;
     static_assert((NBLK * TPS) % 4 == 0, "every wave must issue the same number of DMA pieces per slab");
-    static_assert(!ULO || SAVE == SV_NONE, "un-scaled activation low parts (epi_pair_u) exist in the inference form only");
+    static_assert(!ULO || SAVE == SV_NONE || sv_fwd(SAVE), "un-scaled activation low parts exist in the forward kernels only");
     f32x16 pacc1 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     f32x16 pacc2 = pacc1;                    // accumulators of the previous tile (epilogue pending)
     f32x16 nbias = pacc1;                    // bias of the NEXT tile: the table is resident in LDS, so it is read
@@ -622,12 +629,12 @@ __device__ __forceinline__ void layer16(Pipe& p, int nb1, int nb2, h16x8 (&bh)[N
                         if ((i * NK) / 8 == ks) {
                             if constexpr (SAVE == SV_ACT) {
                                 float x0, x1;
-                                epi_pair_x<RELU>(pacc1, pacc2, i, oh[2 * (t - 1) + (i >> 2)], ol[2 * (t - 1) + (i >> 2)],
+                                epi_pair_x<RELU, ULO>(pacc1, pacc2, i, oh[2 * (t - 1) + (i >> 2)], ol[2 * (t - 1) + (i >> 2)],
                                                  x0, x1);
                                 save_pair(*sc, bw, t - 1, i, x0, x1);
                             } else if constexpr (SAVE == SV_ACT_H) {
                                 float x0, x1;
-                                epi_pair_x<RELU>(pacc1, pacc2, i, oh[2 * (t - 1) + (i >> 2)], ol[2 * (t - 1) + (i >> 2)], x0, x1);
+                                epi_pair_x<RELU, ULO>(pacc1, pacc2, i, oh[2 * (t - 1) + (i >> 2)], ol[2 * (t - 1) + (i >> 2)], x0, x1);
                                 push_bit(bw[(t - 1) >> 1], x0);
                                 push_bit(bw[(t - 1) >> 1], x1);
                                 if (i & 1) store_frag_h(rowh, cxh, t - 1, i, oh[2 * (t - 1) + (i >> 2)]);
@@ -688,11 +695,11 @@ __device__ __forceinline__ void layer16(Pipe& p, int nb1, int nb2, h16x8 (&bh)[N
         for (int i = 0; i < 8; ++i) {
             if constexpr (SAVE == SV_ACT) {
                 float x0, x1;
-                epi_pair_x<RELU>(pacc1, pacc2, i, oh[2 * (NT - 1) + (i >> 2)], ol[2 * (NT - 1) + (i >> 2)], x0, x1);
+                epi_pair_x<RELU, ULO>(pacc1, pacc2, i, oh[2 * (NT - 1) + (i >> 2)], ol[2 * (NT - 1) + (i >> 2)], x0, x1);
                 save_pair(*sc, bw, NT - 1, i, x0, x1);
             } else if constexpr (SAVE == SV_ACT_H) {
                 float x0, x1;
-                epi_pair_x<RELU>(pacc1, pacc2, i, oh[2 * (NT - 1) + (i >> 2)], ol[2 * (NT - 1) + (i >> 2)], x0, x1);
+                epi_pair_x<RELU, ULO>(pacc1, pacc2, i, oh[2 * (NT - 1) + (i >> 2)], ol[2 * (NT - 1) + (i >> 2)], x0, x1);
                 push_bit(bw[(NT - 1) >> 1], x0);
                 push_bit(bw[(NT - 1) >> 1], x1);
                 if (i & 1) store_frag_h(rowh, cxh, NT - 1, i, oh[2 * (NT - 1) + (i >> 2)]);
@@ -905,7 +912,7 @@ __global__ __launch_bounds__(256) void canonical_f16x3_kernel(const float* __res
                                                               const int* __restrict__ count,
                                                               float* __restrict__ pe_out, float* __restrict__ acts,
                                                               uint32_t* __restrict__ relu_bits) {
-    constexpr bool UL = SAVE == SV_NONE;                        // un-scaled activation low parts (epi_pair_u)
+    constexpr bool UL = true;                                    // un-scaled activation low parts (epi_pair_u): all forward forms
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // sparse launch: only the `*count` samples listed in idx are evaluated (hnrf_compact_samples)
     if (idx != nullptr) {
@@ -1002,7 +1009,7 @@ __global__ __launch_bounds__(256) void nonrigid_f16x3_kernel(const float* __rest
                                                              const int* __restrict__ count,
                                                              float* __restrict__ pe_out, float* __restrict__ acts,
                                                              uint32_t* __restrict__ relu_bits) {
-    constexpr bool UL = SAVE == SV_NONE;                        // un-scaled activation low parts (epi_pair_u)
+    constexpr bool UL = true;                                    // un-scaled activation low parts (epi_pair_u): all forward forms
     extern __shared__ __attribute__((aligned(16))) char smem[];
     if (idx != nullptr) {
         P = *count;
