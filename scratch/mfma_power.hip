@@ -5,6 +5,7 @@
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <vector>
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
@@ -28,8 +29,20 @@ __global__ __launch_bounds__(256) void k(const h16x8* __restrict__ src, float* o
 
 int main(int argc, char** argv) {
     const double seconds = argc > 1 ? atof(argv[1]) : 6.0;
+    // operand kinds (the power limit makes the sustained rate a measure of energy per MFMA):
+    //  0 random in [-2, 2)   1 the same, half of the values zero (post-ReLU)   2 non-negative   3 5-bit mantissas
+    //  4 tiny (1e-5 scale: f16 subnormals, like un-scaled low parts)   5 all zero
+    const int mode = argc > 2 ? atoi(argv[2]) : 0;
     std::vector<_Float16> h(4096 * 8);
-    for (auto& v : h) v = (_Float16)((rand() / (float)RAND_MAX - 0.5f) * 4.0f);
+    for (auto& v : h) {
+        float f = (rand() / (float)RAND_MAX - 0.5f) * 4.0f;
+        if (mode == 1 && (rand() & 1)) f = 0.f;
+        if (mode == 2) f = f < 0 ? -f : f;
+        if (mode == 4) f *= 1e-5f;
+        if (mode == 5) f = 0.f;
+        v = (_Float16)f;
+        if (mode == 3) { unsigned short u; memcpy(&u, &v, 2); u &= 0xFFE0; memcpy(&v, &u, 2); }
+    }
     h16x8* src; float* out;
     hipMalloc((void**)&src, h.size() * 2); hipMemcpy(src, h.data(), h.size() * 2, hipMemcpyHostToDevice);
     const int blocks = 1024, iters = 20000;
@@ -44,6 +57,7 @@ int main(int argc, char** argv) {
         el = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     } while (el < seconds);
     const double mfma = (double)launches * blocks * 4 * iters * 24;
+    printf("mode %d: ", mode);
     printf("pure MFMA: %.2f s, %.1f TFLOP/s f16 (%.1f %% of 2516 nominal)\n", el, mfma * 2 * 16384 / el / 1e12,
            100 * mfma * 2 * 16384 / el / 1e12 / 2516);
     return 0;
