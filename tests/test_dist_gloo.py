@@ -84,8 +84,8 @@ def _worker(rank, world, port, q, mode, use_pose, priors_differ):
         dist.destroy_process_group()
 
 
-def _run(mode, use_pose=True, priors_differ=False):
-    world, port = 2, _free_port()
+def _run(mode, use_pose=True, priors_differ=False, world=2):
+    port = _free_port()
     ctx = mp.get_context('spawn')
     q = ctx.SimpleQueue()
     procs = [ctx.Process(target=_worker, args=(r, world, port, q, mode, use_pose, priors_differ)) for r in range(world)]
@@ -98,15 +98,15 @@ def _run(mode, use_pose=True, priors_differ=False):
     return res
 
 
-def _serial_mean(use_pose=True):
+def _serial_mean(use_pose=True, world=2):
     torch.set_num_threads(2)
     acc = None
-    for rank in range(2):
+    for rank in range(world):
         net = _Toy()
         net.loss(_priors(0), seed=10 + rank, use_pose=use_pose).backward()
         g = {n: (None if p.grad is None else p.grad.numpy().copy()) for n, p in net.named_parameters()}
-        acc = g if acc is None else {n: (None if g[n] is None else (acc[n] + g[n]) / 2) for n in g}
-    return acc
+        acc = g if acc is None else {n: (None if g[n] is None else acc[n] + g[n]) for n in g}
+    return {n: (None if v is None else v / world) for n, v in acc.items()}
 
 
 @pytest.mark.parametrize('mode', ['volume', 'full'])
@@ -125,6 +125,17 @@ def test_gradient_sync_equals_mean_of_rank_gradients(mode):
         assert nbytes < 4 * (25 * 16 ** 3 + 200) and nbytes < 4 * n_dec / 10
     else:
         assert nbytes > 4 * n_dec
+
+
+def test_gradient_sync_at_world_4():
+    """The same with four ranks (what BASELINE config 3 runs): mean of four rank gradients, frames dealt 4 ways."""
+    frames, grads, nbytes, err = _run('volume', world=4)
+    assert err is None, err
+    assert [f[0][0] for f in frames] == [float(i) * (i + 1) for i in range(7)]
+    want = _serial_mean(world=4)
+    for n in want:
+        scale = float(abs(want[n]).max()) + 1e-12
+        assert float(abs(grads[n] - want[n]).max()) <= 4e-6 * scale, n
 
 
 def test_parameters_without_gradient_stay_none():
