@@ -23,9 +23,11 @@ near / far and ray_mask on the device.  ``host_rays=True`` runs the reference's 
 cv2 is not importable here.  What the reference does through it:
   * cv2.Rodrigues (camera_util.py:39, 128): restated by the closed form (``rodrigues_cv``), PARITY UNPINNED
     against OpenCV's own numerics (agrees with the formula to rounding);
-  * cv2.undistort (train.py:355-358): frames whose camera has non-zero ``distortions`` raise;
-  * cv2.resize LANCZOS4 / LINEAR (train.py:400-408): only ``resize_img_scale == 1`` is loaded bit-exactly; other scales
-    go through PIL's Lanczos / bilinear filters and are flagged ``resize_parity='unpinned'`` in the frame.
+  * cv2.undistort (train.py:366-371) and cv2.resize INTER_LANCZOS4 / INTER_LINEAR (train.py:408-417): restated after
+    OpenCV's definitions in imageproc.py (host, numpy) and csrc/hnrf_image.hip (device) -- fixed-point undistortion
+    map and weights, 8-tap Lanczos with float weights and double accumulation, 2x2 box mean for the mask at scale
+    1/2.  The two statements agree bit for bit (tests/test_gpu_image.py); against OpenCV's binaries they are PARITY
+    UNPINNED, and a frame that went through either step says so: ``resize_parity='unpinned'`` (else 'exact').
 """
 import io
 import os
@@ -33,7 +35,7 @@ import pickle
 
 import numpy as np
 
-from . import scene
+from . import imageproc, scene
 from .config import cfg
 
 # ------------------------------------------------------------------------------------------------ safe pickle reader
@@ -310,29 +312,50 @@ class Subject:
         with Image.open(os.path.join(self.image_dir, '%s.png' % frame_name)) as im:
             w, h = im.size
         scale = float(cfg.get('resize_img_scale', 1.0))
-        return (h, w) if scale == 1.0 else (int(round(h * scale)), int(round(w * scale)))
+        return (h, w) if scale == 1.0 else imageproc.resized_size(h, w, scale)
 
-    def load_image(self, frame_name, bg_color):
-        """train.py:351-408 (default branches): alpha-composite the frame over ``bg_color`` (0..255).  Returns
-        img (H, W, 3) float in 0..255, alpha (H, W, 3) in 0..1, and 'exact' | 'unpinned' for the resize step."""
+    def decode_frame(self, frame_name):
+        """The two PNGs of a frame as uint8 (H, W, 3) arrays, mask in 0..255 (train.py:352-364), and the camera's
+        (K, D) when it has lens distortion to remove (train.py:366-371; an all-zero vector is the identity map)."""
         from PIL import Image
-        cam = self.cameras.get(frame_name, {})
-        if 'distortions' in cam and np.any(np.asarray(cam['distortions']) != 0):
-            raise NotImplementedError('frame %s has lens distortion %s: cv2.undistort is not available here; undistort '
-                                      'the images offline' % (frame_name, np.asarray(cam['distortions']).ravel()))
         orig = np.array(Image.open(os.path.join(self.image_dir, '%s.png' % frame_name)).convert('RGB'))
         alpha = np.array(Image.open(os.path.join(self.dataset_path, 'masks', '%s.png' % frame_name)).convert('RGB'))
         if alpha.max() == 1:
             alpha = alpha * 255
-        alpha = alpha / 255.
-        img = alpha * orig + (1.0 - alpha) * np.asarray(bg_color)[None, None, :]
+        cam = self.cameras.get(frame_name, {})
+        lens = None
+        if 'distortions' in cam and np.any(np.asarray(cam['distortions']) != 0):
+            lens = (np.asarray(cam['intrinsics'], np.float64)[:3, :3], imageproc.distortion_vector(cam['distortions']))
+        return orig, alpha.astype(np.uint8), lens
+
+    def load_image(self, frame_name, bg_color):
+        """train.py:351-417 (default branches): undistort image and mask, alpha-composite over ``bg_color`` (0..255),
+        resize by cfg.resize_img_scale.  Returns img (H, W, 3) float in 0..255, alpha (H, W, 3) in 0..1, and
+        'exact' | 'unpinned' (an OpenCV step ran through its restatement, imageproc.py)."""
+        orig, alpha, lens = self.decode_frame(frame_name)
         scale = float(cfg.get('resize_img_scale', 1.0))
-        if scale == 1.0:
-            return img, alpha, 'exact'
-        size = (int(round(img.shape[1] * scale)), int(round(img.shape[0] * scale)))
-        res = lambda a, f: np.stack([np.asarray(Image.fromarray(a[..., c].astype(np.float32), mode='F').resize(size, f))
-                                     for c in range(3)], axis=-1)
-        return res(img, Image.LANCZOS), res(alpha, Image.BILINEAR), 'unpinned'
+        img, a = imageproc.load_step(orig, alpha, bg_color, K=None if lens is None else lens[0],
+                                     D=None if lens is None else lens[1], scale=scale)
+        return img, a, 'exact' if lens is None and scale == 1.0 else 'unpinned'
+
+    def load_image_device(self, frame_name, bg_color, device):
+        """load_image on the GPU (hnrf_image.hip): the decoded PNGs are uploaded as bytes, undistortion, composite and
+        resize run there.  Returns img / 255 as float32 (H, W, 3) on the device (what the frame dicts carry as
+        ``raw_rgbs``), the resized mask's first channel (float32 (H, W)), and the parity flag."""
+        import torch
+        from . import ops
+        orig, alpha, lens = self.decode_frame(frame_name)
+        scale = float(cfg.get('resize_img_scale', 1.0))
+        up = lambda a: torch.from_numpy(np.ascontiguousarray(a)).pin_memory().to(device, non_blocking=True)
+        with torch.cuda.device(device):
+            o, a = up(orig), up(alpha)
+            if lens is not None:
+                o, a = ops.undistort_image(o, *lens), ops.undistort_image(a, *lens)
+            bg = up(np.asarray(bg_color, dtype=np.float32))
+            Hd, Wd = imageproc.resized_size(o.shape[0], o.shape[1], scale) if scale != 1.0 else o.shape[:2]
+            img = ops.composite_windows(o, a, bg, [(0, 0)], Hd, Wd, scale=scale)[0]
+            mask = ops.resize_mask(a, scale)
+        return img, mask, 'exact' if lens is None and scale == 1.0 else 'unpinned'
 
 
 class DeviceFrameCache:
@@ -359,32 +382,32 @@ class DeviceFrameCache:
     def _build(self, idx):
         import torch
         from . import ops
-        from PIL import Image
         subj, dev = self.subject, self.device
         name = subj.framelist[idx]
         info, cam = subj.mesh_infos[name], subj.cameras[name]
-        if float(cfg.get('resize_img_scale', 1.0)) != 1.0:
-            raise NotImplementedError('DeviceFrameCache keeps the PNGs as decoded: resize the images offline or use '
-                                      'Subject.train_frame (cfg.resize_img_scale = %s)' % cfg.resize_img_scale)
-        if 'distortions' in cam and np.any(np.asarray(cam['distortions']) != 0):
-            raise NotImplementedError('frame %s has lens distortion: undistort the images offline' % name)
-        orig = np.array(Image.open(os.path.join(subj.image_dir, '%s.png' % name)).convert('RGB'))
-        alpha = np.array(Image.open(os.path.join(subj.dataset_path, 'masks', '%s.png' % name)).convert('RGB'))
-        if alpha.max() == 1:
-            alpha = alpha * 255
-        H, W = orig.shape[:2]
+        scale = float(cfg.get('resize_img_scale', 1.0))
+        orig, alpha, lens = subj.decode_frame(name)
         K = cam['intrinsics'][:3, :3].copy()
+        K[:2] *= scale
         E = apply_global_tfm_to_camera(cam['extrinsics'], info['Rh'].astype('float32'), info['Th'].astype('float32'))
         bbox = info['bbox']
+        up = lambda a: torch.from_numpy(np.ascontiguousarray(a)).pin_memory().to(dev, non_blocking=True)
         with torch.cuda.device(dev):
+            # the frame's two byte images stay resident at their SOURCE resolution, undistorted once (train.py:366-371);
+            # composite + Lanczos run per item on the few windows it needs (hnrf_composite_windows)
+            o, a = up(orig), up(alpha)
+            if lens is not None:
+                o, a = ops.undistort_image(o, *lens), ops.undistort_image(a, *lens)
+            H, W = imageproc.resized_size(o.shape[0], o.shape[1], scale) if scale != 1.0 else tuple(o.shape[:2])
+            subject_mask = (ops.resize_mask(a, scale) > 0).cpu().numpy()          # train.py:626 ``alpha[:, :, 0] > 0.``
             g = ops.gen_rays(K.astype('float32'), E.astype('float32'), np.asarray(bbox['min_xyz'], 'float32'),
                              np.asarray(bbox['max_xyz'], 'float32'), H, W, device=dev)
         ray_mask = g['ray_mask'].cpu().numpy()
-        ent = {'name': name, 'H': H, 'W': W,
+        ent = {'name': name, 'H': H, 'W': W, 'scale': scale,
                'rays': g['rays'][:2].contiguous(), 'near': g['near'].contiguous(), 'far': g['far'].contiguous(),
-               'ray_mask': g['ray_mask'],
-               'orig': torch.from_numpy(orig).to(dev), 'alpha': torch.from_numpy(alpha.astype(np.uint8)).to(dev),
-               'sampler': scene.PatchSampler(ray_mask, alpha[:, :, 0] > 0, ray_mask.reshape(H, W), H, W),
+               'ray_mask': g['ray_mask'], 'orig': o, 'alpha': a,
+               'parity': 'exact' if lens is None and scale == 1.0 else 'unpinned',
+               'sampler': scene.PatchSampler(ray_mask, subject_mask, ray_mask.reshape(H, W), H, W),
                'skeleton': {k: torch.as_tensor(np.ascontiguousarray(v)).to(dev)
                             for k, v in subj._skeleton_entries(info).items()}}
         ent['bytes'] = sum(v.numel() * v.element_size() for v in ent.values() if torch.is_tensor(v))
@@ -416,16 +439,16 @@ class DeviceFrameCache:
         # would read the count back)
         flat_d = up(np.flatnonzero(pinfo['mask']))
         o, d = ent['rays'][0].index_select(0, sel_d), ent['rays'][1].index_select(0, sel_d)
-        crops_o = torch.stack([ent['orig'][y0:y1, x0:x1] for (x0, y0), (x1, y1) in zip(pinfo['xy_min'], pinfo['xy_max'])])
-        crops_a = torch.stack([ent['alpha'][y0:y1, x0:x1] for (x0, y0), (x1, y1) in zip(pinfo['xy_min'], pinfo['xy_max'])])
-        a = crops_a.double() / 255.
-        # float64 like the numpy route (load_image), rounded to float32 once at the end
-        targets = ((a * crops_o.double() + (1.0 - a) * bg_d.double()) / 255.).float()
+        # float64 composite (+ Lanczos at cfg.resize_img_scale) of the windows' pixels only, rounded to float32 once at
+        # the end like the numpy route (load_image, then ``img / 255`` as float32)
+        from . import ops
+        size = int(cfg.patch.size)
+        targets = ops.composite_windows(ent['orig'], ent['alpha'], bg_d, pinfo['xy_min'], size, size, scale=ent['scale'])
         out = {'frame_name': ent['name'], 'bgcolor': bg_d, 'img_width': ent['W'], 'img_height': ent['H'],
                'ray_mask': ent['ray_mask'], 'rays': torch.stack([o, d, d], 0),
                'near': ent['near'].index_select(0, sel_d), 'far': ent['far'].index_select(0, sel_d),
                'patch_div_indices': torch.from_numpy(div), 'patch_masks': masks_d, 'target_patches': targets,
-               'target_rgbs': targets.reshape(-1, 3).index_select(0, flat_d), 'resize_parity': 'exact'}
+               'target_rgbs': targets.reshape(-1, 3).index_select(0, flat_d), 'resize_parity': ent['parity']}
         out.update(ent['skeleton'])
         return out
 
@@ -444,8 +467,7 @@ class FrameStream:
         import threading
         import torch
         if device_cache is None:                      # default: frames stay resident on a GPU (DeviceFrameCache)
-            device_cache = device is not None and torch.device(device).type == 'cuda' and \
-                float(cfg.get('resize_img_scale', 1.0)) == 1.0
+            device_cache = device is not None and torch.device(device).type == 'cuda'
         self.cache = DeviceFrameCache(subject, device) if device_cache else None
         self.subject, self.rank, self.world, self.seed = subject, int(rank), int(world), int(seed)
         self.device, self.bgcolor = device, bgcolor

@@ -622,3 +622,106 @@ def gen_rays(K, E, bbox_min, bbox_max, H, W, device=None):
     N = int(count.item())
     o, d = rays_o[:N], rays_d[:N]
     return {'rays': torch.stack([o, d, d], 0), 'near': near[:N, None], 'far': far[:N, None], 'ray_mask': mask.bool()}
+
+
+# ------------------------------------------------------------------------------------------------ image pre-processing
+# (hnrf_image.hip; the host statement of the same OpenCV functions is imageproc.py)
+_image_consts = {}                    # (kind, key..., device) -> device tensors built once per camera / image size
+
+
+def _upload(arr, device):
+    """Small host array -> device through pinned memory (a pageable copy would wait for the stream's queue)."""
+    t = torch.from_numpy(arr)
+    return t.pin_memory().to(device, non_blocking=True) if torch.device(device).type == 'cuda' else t.to(device)
+
+
+def _u8_image(t, what):
+    if not (torch.is_tensor(t) and t.is_cuda and t.dtype == torch.uint8 and t.is_contiguous() and t.dim() == 3):
+        raise _lib.HnrfError('%s must be a contiguous uint8 (H, W, C) tensor on the GPU' % what)
+
+
+def undistort_image(img, K, D):
+    """cv2.undistort(img, K, D) (train.py:366-371) of a uint8 (H, W, C) image on the device -> new tensor.  K (3,3),
+    D (5,) host arrays; the per-camera constants (stripe inverses) are uploaded once per camera and image size."""
+    import numpy as np
+    from . import imageproc
+    lib = _lib.load()
+    _u8_image(img, 'undistort_image: img')
+    H, W, C = img.shape
+    A = np.asarray(K, dtype=np.float64)[:3, :3]
+    d = imageproc.distortion_vector(D)
+    key = ('undistort', A.tobytes(), d.tobytes(), H, W, img.device)
+    c = _image_consts.get(key)
+    if c is None:
+        rows, ir = imageproc.undistort_stripes(A, H, W)
+        cam = np.concatenate([[A[0, 0], A[1, 1], A[0, 2], A[1, 2]], d])
+        c = _image_consts[key] = (_upload(cam, img.device), _upload(np.ascontiguousarray(ir), img.device), len(ir), rows)
+    out = torch.empty_like(img)
+    _lib.check(lib.hnrf_undistort_image(img.data_ptr(), H, W, C, c[0].data_ptr(), c[1].data_ptr(), c[2], c[3],
+                                        out.data_ptr(), _stream()), 'hnrf_undistort_image')
+    return out
+
+
+def _resize_tables(Hs, Ws, scale, kind, device):
+    import numpy as np
+    from . import imageproc
+    key = ('tables', Hs, Ws, float(scale), kind, device)
+    t = _image_consts.get(key)
+    if t is None:
+        Hd, Wd = imageproc.resized_size(Hs, Ws, scale)
+        inv = 1.0 / float(scale)
+        xo, xw = imageproc.resize_tables(Ws, Wd, inv, kind)
+        yo, yw = imageproc.resize_tables(Hs, Hd, inv, kind)
+        t = _image_consts[key] = (Hd, Wd) + tuple(_upload(np.ascontiguousarray(a), device) for a in (xo, xw, yo, yw))
+    return t
+
+
+def composite_windows(orig, alpha, bgcolor, windows, ph, pw, scale=1.0):
+    """float32 [n, ph, pw, 3] = pixels of ``load_image(...)[0] / 255`` (train.py:406-417: composite over ``bgcolor``
+    (0..255, float32 [3] on the device), then INTER_LANCZOS4 to ``scale``) inside the n windows whose top-left
+    destination pixels are ``windows`` ((n, 2) of (x0, y0): host ints, checked here).  orig / alpha: uint8 (Hs, Ws, 3)
+    on the device, already undistorted.  One whole image = one window at (0, 0)."""
+    import numpy as np
+    from . import imageproc
+    lib = _lib.load()
+    _u8_image(orig, 'composite_windows: orig')
+    _u8_image(alpha, 'composite_windows: alpha')
+    _chk(bgcolor)
+    Hs, Ws, C = orig.shape
+    assert C == 3 and alpha.shape == orig.shape and bgcolor.numel() == 3
+    win = np.ascontiguousarray(np.asarray(windows, dtype=np.int32).reshape(-1, 2))
+    resize = 0 if float(scale) == 1.0 else 1
+    if resize:
+        Hd, Wd, xo, xw, yo, yw = _resize_tables(Hs, Ws, scale, 'lanczos4', orig.device)
+    else:
+        Hd, Wd, xo, xw, yo, yw = Hs, Ws, None, None, None, None
+    if len(win) == 0 or win.min() < 0 or (win[:, 0] + pw).max() > Wd or (win[:, 1] + ph).max() > Hd:
+        raise _lib.HnrfError('composite_windows: windows %s of %dx%d leave the %dx%d image' % (win.tolist(), ph, pw, Hd, Wd))
+    win_d = _upload(win, orig.device)
+    out = torch.empty(len(win), ph, pw, 3, device=orig.device)
+    _lib.check(lib.hnrf_composite_windows(orig.data_ptr(), alpha.data_ptr(), Hs, Ws, bgcolor.data_ptr(), resize, _ptr(xo),
+                                          _ptr(xw), _ptr(yo), _ptr(yw), Hd, Wd, win_d.data_ptr(), len(win), ph, pw,
+                                          out.data_ptr(), _stream()), 'hnrf_composite_windows')
+    return out
+
+
+def resize_mask(alpha, scale, channel=0):
+    """float32 (Hd, Wd): channel ``channel`` of ``cv2.resize(alpha / 255, fx=scale, fy=scale, INTER_LINEAR)``
+    (train.py:413-417); at scale 1 the channel / 255 itself."""
+    from . import imageproc
+    lib = _lib.load()
+    _u8_image(alpha, 'resize_mask: alpha')
+    Hs, Ws, C = alpha.shape
+    assert C == 3
+    if float(scale) == 1.0:
+        return (alpha[:, :, channel].double() / 255.).float()
+    Hd, Wd = imageproc.resized_size(Hs, Ws, scale)
+    out = torch.empty(Hd, Wd, device=alpha.device)
+    if imageproc.is_half_scale(scale) and 2 * Hd <= Hs and 2 * Wd <= Ws:
+        _lib.check(lib.hnrf_resize_mask(alpha.data_ptr(), Hs, Ws, channel, 2, 0, 0, 0, 0, Hd, Wd, out.data_ptr(), _stream()),
+                   'hnrf_resize_mask')
+    else:
+        _, _, xo, xw, yo, yw = _resize_tables(Hs, Ws, scale, 'linear', alpha.device)
+        _lib.check(lib.hnrf_resize_mask(alpha.data_ptr(), Hs, Ws, channel, 1, xo.data_ptr(), xw.data_ptr(), yo.data_ptr(),
+                                        yw.data_ptr(), Hd, Wd, out.data_ptr(), _stream()), 'hnrf_resize_mask')
+    return out

@@ -314,3 +314,87 @@ def synthetic_frame(H=512, W=512, pose_seed=0, pose_scale=0.2, focal_at_512=1700
         'ray_mask': hit,
         **common,
     }
+
+
+# ------------------------------------------------------------------------------------------------ synthetic subject
+# A subject DIRECTORY in the reference's on-disk layout (tools/prepare_zju_mocap/prepare_dataset.py:172-221) made of
+# analytic content: no dataset is obtainable offline, and with closed-form images the image pre-processing
+# (undistortion, resize) can be checked against the function it should recover.
+ZJU_LIKE_DISTORTION = (-0.27, 0.11, -3e-4, 6e-4, -0.02)      # k1 k2 p1 p2 k3: the size ZJU-MoCap's calibration reports
+
+
+def analytic_image(x, y, size, seed=0):
+    """Smooth RGB pattern (0..255 float64, shape x.shape + (3,)) of the undistorted pixel coordinates; wavelengths of
+    size/6 pixels and longer, so bilinear / Lanczos interpolation errors stay far below one grey level."""
+    rs = np.random.RandomState(1000 + seed)
+    out = []
+    for _ in range(3):
+        a, b, c, d = rs.uniform(3.0, 6.0, 4) * 2 * np.pi / size
+        p, q = rs.uniform(0, 2 * np.pi, 2)
+        out.append(127.5 + 60.0 * np.sin(a * x + b * y + p) + 55.0 * np.cos(c * x - d * y + q))
+    return np.stack(out, axis=-1)
+
+
+def analytic_mask(x, y, size):
+    """Soft-edged ellipse (0..255 float64): 255 inside, a ramp of ~size/40 pixels to 0."""
+    r = np.sqrt(((y - size / 2) / (size * 0.4)) ** 2 + ((x - size / 2) / (size * 0.2)) ** 2)
+    return np.clip((1.0 - r) * 16.0, 0.0, 1.0) * 255.0
+
+
+def distort_pixels(x, y, K, D):
+    """Brown-Conrady forward model: undistorted pixel -> where the lens images it (the map cv2.undistort samples)."""
+    k1, k2, p1, p2, k3 = [float(v) for v in D]
+    xn, yn = (x - K[0, 2]) / K[0, 0], (y - K[1, 2]) / K[1, 1]
+    r2 = xn * xn + yn * yn
+    kr = 1 + ((k3 * r2 + k2) * r2 + k1) * r2
+    xd = xn * kr + 2 * p1 * xn * yn + p2 * (r2 + 2 * xn * xn)
+    yd = yn * kr + p1 * (r2 + 2 * yn * yn) + 2 * p2 * xn * yn
+    return K[0, 0] * xd + K[0, 2], K[1, 1] * yd + K[1, 2]
+
+
+def undistort_pixels(u, v, K, D, iters=30):
+    """Inverse of distort_pixels by fixed-point iteration (converges for the mild lenses used here)."""
+    k1, k2, p1, p2, k3 = [float(t) for t in D]
+    xd, yd = (u - K[0, 2]) / K[0, 0], (v - K[1, 2]) / K[1, 1]
+    xn, yn = xd.copy(), yd.copy()
+    for _ in range(iters):
+        r2 = xn * xn + yn * yn
+        kr = 1 + ((k3 * r2 + k2) * r2 + k1) * r2
+        dx = 2 * p1 * xn * yn + p2 * (r2 + 2 * xn * xn)
+        dy = p1 * (r2 + 2 * yn * yn) + 2 * p2 * xn * yn
+        xn, yn = (xd - dx) / kr, (yd - dy) / kr
+    return K[0, 0] * xn + K[0, 2], K[1, 1] * yn + K[1, 2]
+
+
+def write_synthetic_subject(out_dir, n_frames=4, size=512, distortions=None, seed=0, radius=4.0, binary_mask=False):
+    """Write cameras.pkl / mesh_infos.pkl / canonical_joints.pkl / images / masks for ``n_frames`` frames of
+    ``size`` x ``size`` pixels.  With ``distortions`` (k1 k2 p1 p2 k3) the PNGs hold what such a lens would record of
+    analytic_image / analytic_mask, i.e. undistorting them must give those functions back on the pixel grid.
+    Returns the frame names."""
+    import os
+    import pickle
+    from PIL import Image
+    os.makedirs(os.path.join(out_dir, 'images'), exist_ok=True)
+    os.makedirs(os.path.join(out_dir, 'masks'), exist_ok=True)
+    rs = np.random.RandomState(seed)
+    J = TPOSE_JOINTS.astype(np.float64)
+    D = np.zeros(5) if distortions is None else np.asarray(distortions, dtype=np.float64)
+    cams, infos, names = {}, {}, []
+    vv, uu = np.mgrid[0:size, 0:size].astype(np.float64)
+    for n in range(n_frames):
+        name = 'frame_%06d' % n
+        names.append(name)
+        K, E = tpose_camera(np.array([size, size], dtype=np.float32), radius, 1250.0 * size / 512.0)
+        K = K.astype(np.float64)
+        cams[name] = {'intrinsics': K, 'extrinsics': E.astype(np.float64), 'distortions': D.copy()}
+        infos[name] = {'Rh': np.zeros(3), 'Th': np.zeros(3), 'poses': rs.randn(72) * 0.1, 'joints': J, 'tpose_joints': J}
+        x, y = (uu, vv) if not np.any(D) else undistort_pixels(uu, vv, K, D)
+        img = np.clip(np.rint(analytic_image(x, y, size, seed=n)), 0, 255).astype(np.uint8)
+        m = analytic_mask(x, y, size)
+        m = np.where(m > 127.5, 255.0, 0.0) if binary_mask else np.rint(m)
+        Image.fromarray(img).save(os.path.join(out_dir, 'images', name + '.png'))
+        Image.fromarray(np.stack([m.astype(np.uint8)] * 3, -1)).save(os.path.join(out_dir, 'masks', name + '.png'))
+    for fname, obj in (('cameras.pkl', cams), ('mesh_infos.pkl', infos), ('canonical_joints.pkl', {'joints': J})):
+        with open(os.path.join(out_dir, fname), 'wb') as f:
+            pickle.dump(obj, f)
+    return names

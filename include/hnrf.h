@@ -340,6 +340,36 @@ int hnrf_gen_rays(const float* Kinv, const float* R, const float* T, const float
                   int H, int W, float* rays_o, float* rays_d, float* near, float* far, uint8_t* ray_mask,
                   int* count, void* workspace, size_t workspace_bytes, void* stream);
 
+/* ---- image pre-processing of Dataset.load_image (core/data/human_nerf/train.py:351-417, freeview.py:137-166) ----
+ * The reference decodes a frame's image and mask PNGs and runs cv2.undistort on both (train.py:366-371: every
+ * prepared ZJU-MoCap camera has `distortions`, tools/prepare_zju_mocap/prepare_dataset.py:172-176), composites
+ * mask/255 * image + (1 - mask/255) * bgcolor in float64 (train.py:406) and, for resize_img_scale != 1 (0.5 in
+ * every 387 / wild yaml), cv2.resize with INTER_LANCZOS4 (image) and INTER_LINEAR (mask) (train.py:408-417).
+ * humannerf_amd/imageproc.py is the host statement of the same OpenCV functions (cv2 is not importable: parity with
+ * OpenCV's binaries is unpinned; the two statements agree bit for bit).
+ *
+ * hnrf_undistort_image: src / dst uint8 [H,W,C] (C <= 4, not in place).  cam = {fx, fy, u0, v0, k1, k2, p1, p2, k3}
+ *  and ir = [n_stripes][9] row-major inverses of K with its principal point moved to the stripe's first row
+ *  (cv2.undistort works in stripes of stripe_rows = min(max(1, 4096 / W), H) rows), both float64 DEVICE arrays.
+ *  Fixed-point map (1/32 pixel), bilinear taps with remap's 15-bit weights, constant 0 outside the image. */
+int hnrf_undistort_image(const uint8_t* src, int H, int W, int C, const double* cam, const double* ir, int n_stripes,
+                         int stripe_rows, uint8_t* dst, void* stream);
+/* hnrf_composite_windows: orig / alpha uint8 [Hs,Ws,3] (alpha in 0..255), bgcolor float32 [3] in 0..255 ->
+ *  out float32 [n_win, ph, pw, 3] = composite / 255 for the windows whose top-left DESTINATION pixels are
+ *  win_xy[n_win][2] = (x0, y0) (int32, device; windows must lie inside [Hd, Wd]).  resize = 0: destination grid =
+ *  source grid (Hd == Hs, Wd == Ws, tables ignored).  resize = 1: INTER_LANCZOS4 from the coefficient tables of
+ *  hal::resize's setup loop -- xofs [Wd] / yofs [Hd] int32 (index of the tap left of the sample point), xw [Wd][8] /
+ *  yw [Hd][8] float32 -- horizontal then vertical pass over the float64 composite, taps clamped to the border.
+ *  A training item's 6 windows of 32x32 (cfg.patch) or a whole image (one window) alike. */
+int hnrf_composite_windows(const uint8_t* orig, const uint8_t* alpha, int Hs, int Ws, const float* bgcolor, int resize,
+                           const int* xofs, const float* xw, const int* yofs, const float* yw, int Hd, int Wd,
+                           const int* win_xy, int n_win, int ph, int pw, float* out, void* stream);
+/* hnrf_resize_mask: channel `channel` of the uint8 mask [Hs,Ws,3], divided by 255, through cv2.resize INTER_LINEAR ->
+ *  out float32 [Hd,Wd] (the dataset only asks whether it is > 0: train.py:620-631).  mode 1: two-tap tables
+ *  (xw [Wd][2], yw [Hd][2]); mode 2: the 2x2 box mean hal::resize substitutes at scale exactly 1/2. */
+int hnrf_resize_mask(const uint8_t* alpha, int Hs, int Ws, int channel, int mode, const int* xofs, const float* xw,
+                     const int* yofs, const float* yw, int Hd, int Wd, float* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

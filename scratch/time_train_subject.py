@@ -1,10 +1,10 @@
-"""Scratch: end-to-end training rate from a prepared subject directory (512x512 synthetic subject, 16 frames):
+"""End-to-end training rate from a prepared subject directory (synthetic subject, 16 frames, rendered at 512x512):
 data side = dataset.FrameStream with the device-resident frame cache vs the numpy route.
-    python scratch/time_train_subject.py [iters]"""
-import os, pickle, sys, tempfile, time
+    python scratch/time_train_subject.py [iters] [lens]
+``lens``: 1024x1024 source PNGs with lens distortion and cfg.resize_img_scale = 0.5 (the ZJU-387 / wild setting)."""
+import os, sys, tempfile, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
-from PIL import Image
 from humannerf_amd import dataset, scene
 from humannerf_amd.config import cfg
 from humannerf_amd.network import Network
@@ -12,23 +12,12 @@ from humannerf_amd.seeded import default_shapes, seeded_state
 from humannerf_amd.train import Trainer
 
 iters = int(sys.argv[1]) if len(sys.argv) > 1 else 60
+# "lens": what every 387 / wild yaml configures -- 1024x1024 PNGs, `distortions` on every camera, resize_img_scale 0.5
+lens = len(sys.argv) > 2 and sys.argv[2] == 'lens'
 d = tempfile.mkdtemp()
-os.makedirs(d + '/images'); os.makedirs(d + '/masks')
-H = W = 512
-J = scene.TPOSE_JOINTS.astype(np.float64)
-cams, infos = {}, {}
-rs = np.random.RandomState(0)
-for n in range(16):
-    name = 'f%03d' % n
-    K, E = scene.tpose_camera(np.array([W, H], dtype=np.float32), 4.0, 1250.0)
-    cams[name] = {'intrinsics': K.astype(np.float64), 'extrinsics': E.astype(np.float64), 'distortions': np.zeros(5)}
-    infos[name] = {'Rh': np.zeros(3), 'Th': np.zeros(3), 'poses': rs.randn(72) * 0.1, 'joints': J, 'tpose_joints': J}
-    yy, xx = np.mgrid[0:H, 0:W]
-    m = ((yy - H / 2) ** 2 / (H * 0.4) ** 2 + (xx - W / 2) ** 2 / (W * 0.2) ** 2 < 1)
-    Image.fromarray((np.stack([m] * 3, -1) * 255).astype(np.uint8)).save(d + '/masks/' + name + '.png')
-    Image.fromarray(rs.randint(0, 255, (H, W, 3)).astype(np.uint8)).save(d + '/images/' + name + '.png')
-pickle.dump(cams, open(d + '/cameras.pkl', 'wb')); pickle.dump(infos, open(d + '/mesh_infos.pkl', 'wb'))
-pickle.dump({'joints': J}, open(d + '/canonical_joints.pkl', 'wb'))
+scene.write_synthetic_subject(d, n_frames=16, size=1024 if lens else 512, binary_mask=True,
+                              distortions=scene.ZJU_LIKE_DISTORTION if lens else None)
+cfg.resize_img_scale = 0.5 if lens else 1.0
 
 dev = torch.device('cuda:0')
 cfg.train.lossweights.lpips, cfg.N_samples = 0.0, 128

@@ -150,13 +150,18 @@ def test_pickle_reader_refuses_code(golden_dir, tmp_path):
     assert np.array_equal(back['k'], ok['k']) and back['n'] == 2.5 and back['l'] == ok['l']
 
 
-def test_distorted_cameras_are_refused(subj):
+def test_distorted_cameras_load(subj):
+    """Round 2 refused such frames; cv2.undistort is restated now (imageproc.py, tests/test_image_cpu.py).  Lens models
+    beyond the 5-vector the ZJU preparer writes (prepare_dataset.py:172-176) are refused by name."""
     name = NAMES[0]
     old = subj.cameras[name]['distortions']
-    subj.cameras[name]['distortions'] = np.array([0.1, 0, 0, 0, 0.])
     try:
-        with pytest.raises(NotImplementedError, match='undistort'):
-            subj.load_image(name, np.zeros(3))
+        subj.cameras[name]['distortions'] = np.array([0.1, 0, 0, 0, 0.])
+        img, alpha, flag = subj.load_image(name, np.zeros(3, dtype=np.float32))
+        assert flag == 'unpinned' and img.shape == (H, W, 3)
+        subj.cameras[name]['distortions'] = np.array([0.1, 0, 0, 0, 0., 0.2, 0, 0])
+        with pytest.raises(NotImplementedError, match='rational'):
+            subj.load_image(name, np.zeros(3, dtype=np.float32))
     finally:
         subj.cameras[name]['distortions'] = old
 
