@@ -16,7 +16,14 @@ Extra objects on that line:
                   launch stream, against the MFMA peak of the arithmetic used.
   cpu_baseline -- the CPU oracle (port of the reference path, parity-pinned by
                   tests/test_oracle_golden.py) timed on this host on a bounded
-                  sample of the same frame; rank 0, N = 1 only.
+                  sample of the same frame: one warm-up, median of 3, at 8 threads
+                  and at torch's default thread count (BASELINE.md section 4);
+                  `value` is the faster of the two; rank 0, N = 1 only.
+  eager_rocm_baseline -- north_star's comparator ("the reference PyTorch renderer on
+                  1 MI355X"): the same op-faithful restatement executed eagerly by
+                  PyTorch-ROCm on this GPU (same 32768-ray / 300000-sample chunking),
+                  whole frame and one training step, with the ratio to `value`.
+                  A checker leg like cpu_baseline: after the timed region, rank 0, N = 1.
 """
 import argparse
 import json
@@ -65,7 +72,7 @@ def main():
     ap.add_argument('--warmup', type=int, default=1)
     ap.add_argument('--mode', default=os.environ.get('HNRF_MLP_MODE', 'f16x3'), choices=['f32', 'f16x3'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--cpu-rays', type=int, default=4096)
+    ap.add_argument('--cpu-rays', type=int, default=2048)
     ap.add_argument('--train-steps', type=int, default=10, help='extra: timed training iterations (0 = skip)')
     ap.add_argument('--lean', action='store_true', help='headline loop returns rgb/alpha/depth only')
     ap.add_argument('--main-only', action='store_true',
@@ -73,6 +80,11 @@ def main():
                          'so that a rocprofv3 --stats average covers exactly the launches behind `roofline`')
     args = ap.parse_args()
 
+    if 'HNRF_BENCH_DEVICE' not in os.environ and torch.cuda.device_count() < args.gpus:
+        # (device_count() does not initialise the GPU: safe in the launcher too)
+        sys.exit('bench.py: --gpus %d but this node shows %d GPU(s) (torch.cuda.device_count()); one rank per GPU is '
+                 'the contract -- set HNRF_BENCH_DEVICE=0 HNRF_DIST_BACKEND=gloo to rehearse N ranks on one card'
+                 % (args.gpus, torch.cuda.device_count()))
     if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
         # plain `python bench.py --gpus N`: this process becomes the launcher.  It has not touched the GPU (importing
         # torch does not), starts one fresh process per GPU with the torchrun environment and relays rank 0's line.
@@ -193,6 +205,8 @@ def main():
                                + '; seeded random weights of the default architecture',
                    'rays_per_step_per_gpu': R, 'samples_per_ray': S, 'ray_chunk': int(cfg.chunk),
                    'mlp_mode': args.mode, 'parallelism': 'frames sharded over %d GPU(s), no collective' % world},
+        'dist_backend': 'none' if dist is None else dist.get_backend(),       # 'nccl' IS RCCL on ROCm
+        'dist_world_size': 1 if dist is None else dist.get_world_size(),
         'roofline': roofline,
         'algorithmic_tflops': round(world * R * S * args.steps * 2.0 * (CNL_MAC_PER_SAMPLE + NR_MAC_PER_SAMPLE)
                                     / elapsed / 1e12, 2),
@@ -362,21 +376,81 @@ def main():
         cfg.perturb = 0.
 
     if rank == 0 and world == 1 and extras and not args.no_cpu_baseline:
-        # bounded sample of the same workload: every (R/cpu_rays)-th ray of the frame
         from oracle import oracle
+        # ---- north_star's comparator: the reference's op sequence executed eagerly by PyTorch-ROCm on this GPU ----
+        state_gpu = {k: torch.from_numpy(v).to(dev) for k, v in state.items()}
+
+        def eager_frame():
+            with torch.no_grad():
+                return oracle.render(state_gpu, fr, iter_val=float(cfg.eval_iter), N_samples=S, device=dev, use_grid_sample=True)
+        eager_frame()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        ref_gpu = eager_frame()
+        torch.cuda.synchronize()
+        dt_e = time.perf_counter() - t0
+        eager = {'value': round(R / dt_e, 1), 'unit': 'rays/s', 'ms_per_frame': round(dt_e * 1e3, 1),
+                 'kind': 'port: the oracle\'s op-faithful restatement of network.py (F.grid_sample x 24, nn.Linear chains, '
+                         'torch.cumprod; 32768-ray / 300000-sample chunking) run by PyTorch-ROCm eager ops on this GPU -- '
+                         'not the reference source, which cannot travel to the GPU box',
+                 'sample': 'the whole frame (%d rays x %d samples, all 11 outputs), 1 warm-up + 1 timed' % (R, S),
+                 'ratio_vs_value': round(result['value'] / (R / dt_e), 2),
+                 'max_abs_rgb_diff_vs_value': float((out['rgb'] - ref_gpu['rgb']).abs().max())}
+        del ref_gpu
+        if 'train' in result:
+            st = {k: v.clone().requires_grad_(True) for k, v in state_gpu.items()}
+            opt = torch.optim.Adam(list(st.values()), lr=5e-4)
+            sub_t = dict(fr)
+            ii = idx.cpu().numpy()
+            sub_t['rays'], sub_t['near'], sub_t['far'] = fr['rays'][:, ii], fr['near'][ii], fr['far'][ii]
+
+            def eager_step():
+                opt.zero_grad(set_to_none=True)
+                o = oracle.render(st, sub_t, iter_val=float(cfg.eval_iter), N_samples=S, device=dev, use_grid_sample=True)
+                (0.2 * torch.mean((o['rgb'] - tb['target_rgbs']) ** 2)).backward()
+                opt.step()
+            for _ in range(2):
+                eager_step()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(3):
+                eager_step()
+            torch.cuda.synchronize()
+            dt_et = (time.perf_counter() - t0) / 3
+            eager['train'] = {'ms_per_iter': round(dt_et * 1e3, 2), 'iters_per_s': round(1.0 / dt_et, 3),
+                              'ratio_vs_train': round(dt_et * 1e3 / result['train']['ms_per_iter'], 2),
+                              'sample': 'the same %d rays x %d samples, MSE loss, torch.optim.Adam; 2 warm-up + 3 timed'
+                                        % (len(ii), S)}
+            del st, opt
+        del state_gpu
+        torch.cuda.empty_cache()
+        result['eager_rocm_baseline'] = eager
+
+        # ---- CPU: bounded sample of the same workload (every (R/cpu_rays)-th ray of the frame) ----
         stride = max(1, R // args.cpu_rays)
         sub = dict(fr)
         sub['rays'] = fr['rays'][:, ::stride]
         sub['near'], sub['far'] = fr['near'][::stride], fr['far'][::stride]
         n = sub['rays'].shape[1]
-        t0 = time.perf_counter()
-        ref = oracle.render(state, sub, iter_val=float(cfg.eval_iter), N_samples=S)
-        dt = time.perf_counter() - t0
+        default_threads = torch.get_num_threads()
+        runs, ref = [], None
+        for threads in sorted({min(8, default_threads), default_threads}):
+            torch.set_num_threads(threads)
+            oracle.render(state, sub, iter_val=float(cfg.eval_iter), N_samples=S)            # warm-up
+            ts = []
+            for _ in range(3):
+                t0 = time.perf_counter()
+                ref = oracle.render(state, sub, iter_val=float(cfg.eval_iter), N_samples=S)
+                ts.append(time.perf_counter() - t0)
+            runs.append({'cores': threads, 'value': round(n / float(np.median(ts)), 1), 'median_s': round(float(np.median(ts)), 3),
+                         'runs_s': [round(t, 3) for t in ts]})
+        torch.set_num_threads(default_threads)
+        best = max(runs, key=lambda r: r['value'])
         err = float((out['rgb'][::stride].cpu() - ref['rgb']).abs().max())
-        result['cpu_baseline'] = {'value': round(n / dt, 1), 'unit': 'rays/s', 'cores': torch.get_num_threads(),
-                                  'kind': 'port', 'host_cpus': os.cpu_count(),
-                                  'sample': '%d rays x %d samples (every %d-th ray of the same frame), torch CPU '
-                                            'fp32 oracle, %.1f s' % (n, S, stride, dt),
+        result['cpu_baseline'] = {'value': best['value'], 'unit': 'rays/s', 'cores': best['cores'],
+                                  'kind': 'port', 'host_cpus': os.cpu_count(), 'by_threads': runs,
+                                  'sample': '%d rays x %d samples (every %d-th ray of the same frame), torch CPU fp32 oracle; '
+                                            'per thread count 1 warm-up + median of 3' % (n, S, stride),
                                   'max_abs_rgb_diff_gpu_vs_cpu': err}
     if rank == 0:
         print(json.dumps(result))

@@ -18,6 +18,8 @@ SIGNATURES = {
     'hnrf_last_error': (ctypes.c_char_p, []),
     'hnrf_sample_warp_fwd': (_int, [_vp] * 10 + [_i64, _int, _int, _int] + [_vp] * 4 + [_vp]),
     'hnrf_nonrigid_packed_bytes': (_sz, [_int]),
+    'hnrf_canonical_status_offset': (_sz, [_int]),
+    'hnrf_nonrigid_status_offset': (_sz, [_int]),
     'hnrf_nonrigid_pack': (_int, [_vp, _vp, _vp, _int, _vp, _vp]),
     'hnrf_nonrigid_fwd': (_int, [_vp, _vp, _vp, _int, _i64, _vp, _vp, _vp]),
     'hnrf_canonical_packed_bytes': (_sz, [_int]),

@@ -132,6 +132,11 @@ _DEFAULTS = {
         # every this many backward passes the saved activations and the incoming gradient are checked against the
         # range the split-f16 / f16 arithmetic assumes (autograd.OperandRangeGuard); 0 = never
         'train_check_every': 200,
+        # inference in 'f16x3' clamps hidden activations at 65504 (the f16 range).  The kernels flag it (status word of
+        # the packed weight image, read back one frame late without a synchronisation); what Network.forward does when
+        # the flag is up: 'raise' ActivationRangeError | 'f32' = warn and render every later frame with the exact fp32
+        # MFMA kernels (the flagged frames are wrong: render loops re-render them) | 'ignore'
+        'on_f16_range': 'raise',
         # materialise the per-sample diagnostic outputs the reference always
         # returns (backward_motion_weights, xyz_on_rays, ...; ~17 KB/ray).
         'diagnostics': True,

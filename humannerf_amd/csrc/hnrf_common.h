@@ -46,6 +46,8 @@ static inline int reserve_lds(const void* fn, int bytes, unsigned long long& don
 // HNRF_MLP_F16X3 back end (hnrf_mlp_f16.hip)
 size_t canonical16_bytes();
 size_t nonrigid16_bytes();
+size_t canonical16_status_offset();
+size_t nonrigid16_status_offset();
 int canonical16_pack(const float* const* w, const float* const* b, void* packed, hipStream_t st);
 int nonrigid16_pack(const float* const* w, const float* const* b, const float* cond, void* packed, hipStream_t st);
 int canonical16_fwd(const float* xyz, const void* packed, int64_t P, float* raw, const int* idx, const int* count,

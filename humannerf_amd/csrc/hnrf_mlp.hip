@@ -373,6 +373,10 @@ extern "C" size_t hnrf_nonrigid_packed_bytes(int mode) {
     return mode == HNRF_MLP_F32 ? (size_t)NR_FLOATS * sizeof(float) : 0;
 }
 
+// byte offset of the image's status word (HNRF_STATUS_*), 0 = this arithmetic has none (fp32 MFMA cannot leave its range)
+extern "C" size_t hnrf_canonical_status_offset(int mode) { return mode == HNRF_MLP_F16X3 ? canonical16_status_offset() : 0; }
+extern "C" size_t hnrf_nonrigid_status_offset(int mode) { return mode == HNRF_MLP_F16X3 ? nonrigid16_status_offset() : 0; }
+
 extern "C" int hnrf_canonical_pack(const float* const* weights, const float* const* biases, int mode, void* packed,
                                    void* stream) {
     HNRF_REQUIRE(weights && biases && packed, HNRF_E_ARG, "hnrf_canonical_pack: null pointer");

@@ -177,6 +177,9 @@ constexpr int64_t NR16_BIAS = NR16_OUT + NR16_NB_MID * KB;            // 6 layer
 constexpr int NR16_BIAS_LDS = 3 * 1024;
 constexpr int64_t NR16_BYTES = NR16_BIAS + 4 * 1024;
 constexpr int NR16_SLAB = 32 * 1024;                                   // L0 travels as ONE slab of 4 tiles
+// Status word of an image (uint32, in the unused tail of the head's bias record; zeroed by every pack).
+constexpr int64_t CNL16_STATUS = CNL16_BIAS + 8 * 1024 + 512;
+constexpr int64_t NR16_STATUS = NR16_BIAS + 3 * 1024 + 512;
 constexpr int PE_STASH = 32 * 1024;        // per workgroup: 4 waves x 4 k-steps x (hi|lo) x 1 KiB
 
 // ---- device helpers ---------------------------------------------------------
@@ -263,6 +266,7 @@ struct Pipe {
     unsigned ph;         // ring slot of the slab being consumed
     unsigned bias_off;   // byte offset of the current tile's bias record
     int wave;
+    unsigned long long sat;   // lanes whose activations came near the f16 clamp (sat_check_frag)
 #ifdef HNRF_STAMP
     unsigned long long t_last, sum_k, sum_b;   // diagnostic build only: cycles in k-loops / between them
 #endif
@@ -297,8 +301,31 @@ __device__ __forceinline__ void epi_pair(const f32x16& a1, const f32x16& a2, int
 // ABSOLUTE floor of 3e-8 on activations of order 0.1 .. 1 -- what a dot product over them sees is the same.  The
 // products wh . xl then carry no 2^11 and go into the FIRST accumulator; wl keeps its lift (weights are packed
 // offline and 2^-12 |w| would sit far down in the subnormals).
+// f16-range guard of the inference kernels.  The clamp above 65504 is silent: a checkpoint whose hidden activations
+// leave the f16 range would render a wrong image without any error.  When a B-operand fragment is complete (every
+// fourth pair) its 8 non-negative halves are folded with three v_pk_max_u16 and compared -- as integers, which order
+// like the values and put +inf / NaN on top -- against SAT_HALF; the verdict lands in an SGPR pair (no VGPR lives on:
+// these kernels sit at the 256 + 256 register limit, one more live VGPR sent the two-group kernel to scratch), and the
+// kernel ORs HNRF_STATUS_F16_RANGE into the image's status word at its end.  5 VALU per 8 values, in the MFMA shadow.
+constexpr unsigned SAT_HALF = 0x7B53u;      // f16(60000)
+__device__ __forceinline__ void sat_check_frag(const h16x8& hi, unsigned long long& sflag) {
+    typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+    typedef unsigned short u16x8 __attribute__((ext_vector_type(8)));
+    const u16x8 v = __builtin_bit_cast(u16x8, hi);               // (v_pk_max_u16: the float form adds a canonicalising
+    const u16x2 a = {v[0], v[1]}, b = {v[2], v[3]}, c = {v[4], v[5]}, d = {v[6], v[7]};      // v_pk_max per operand)
+    const u16x2 m = __builtin_elementwise_max(__builtin_elementwise_max(a, b), __builtin_elementwise_max(c, d));
+    const unsigned u = __builtin_bit_cast(unsigned, m);
+    asm volatile("v_cmp_le_u32 vcc, %2, %1\n\ts_or_b64 %0, %0, vcc\n\tv_cmp_le_u16 vcc, %3, %1\n\ts_or_b64 %0, %0, vcc"
+                 : "+s"(sflag) : "v"(u), "s"(SAT_HALF << 16), "s"(SAT_HALF) : "vcc");
+}
+__device__ __forceinline__ void raise_f16_range(const char* packed, int64_t off, unsigned long long sflag) {
+    if (sflag != 0ull && (threadIdx.x & 63) == 0)
+        atomicOr(reinterpret_cast<unsigned*>(const_cast<char*>(packed) + off), (unsigned)HNRF_STATUS_F16_RANGE);
+}
+
 template <bool RELU>
-__device__ __forceinline__ void epi_pair_u(const f32x16& a1, const f32x16& a2, int i, h16x8& hi, h16x8& lo) {
+__device__ __forceinline__ void epi_pair_u(const f32x16& a1, const f32x16& a2, int i, h16x8& hi, h16x8& lo,
+                                           unsigned long long& sflag) {
     float x0 = fmaf(a2[2 * i], LO_INV, a1[2 * i]);
     float x1 = fmaf(a2[2 * i + 1], LO_INV, a1[2 * i + 1]);
     if (RELU) {
@@ -318,6 +345,7 @@ __device__ __forceinline__ void epi_pair_u(const f32x16& a1, const f32x16& a2, i
     hi[e + 1] = hh[1];
     lo[e] = ll[0];
     lo[e + 1] = ll[1];
+    if (RELU && (i & 3) == 3) sat_check_frag(hi, sflag);
 }
 __device__ __forceinline__ void split8_u(const float (&v)[8], h16x8& hi, h16x8& lo) {
 #pragma unroll
@@ -619,7 +647,7 @@ __device__ __forceinline__ void layer16(Pipe& p, int nb1, int nb2, h16x8 (&bh)[N
 #pragma unroll
                     for (int i = 0; i < 8; ++i)
                         if ((i * (NK - 1)) / 8 == ks) {
-                            epi_pair_u<true>(*pend1, *pend2, i, bh[NKB - 2 + (i >> 2)], bl[NKB - 2 + (i >> 2)]);
+                            epi_pair_u<true>(*pend1, *pend2, i, bh[NKB - 2 + (i >> 2)], bl[NKB - 2 + (i >> 2)], p.sat);
                             asm volatile("" : "+v"(bh[NKB - 2 + (i >> 2)]), "+v"(bl[NKB - 2 + (i >> 2)]));
                         }
                 }
@@ -651,7 +679,7 @@ __device__ __forceinline__ void layer16(Pipe& p, int nb1, int nb2, h16x8 (&bh)[N
                                 sc->fout[16 * (t - 1) + 2 * i] = fmaf(pacc2[2 * i], LO_INV, pacc1[2 * i]);
                                 sc->fout[16 * (t - 1) + 2 * i + 1] = fmaf(pacc2[2 * i + 1], LO_INV, pacc1[2 * i + 1]);
                             } else
-                            epi_pair_u<RELU>(pacc1, pacc2, i, oh[2 * (t - 1) + (i >> 2)], ol[2 * (t - 1) + (i >> 2)]);
+                            epi_pair_u<RELU>(pacc1, pacc2, i, oh[2 * (t - 1) + (i >> 2)], ol[2 * (t - 1) + (i >> 2)], p.sat);
                             // pin the result here: without a use in this block hipcc sinks the whole
                             // epilogue to the first consumer (the next layer), out of the MFMA shadow
                             if constexpr (SAVE != SV_PE)
@@ -716,7 +744,7 @@ __device__ __forceinline__ void layer16(Pipe& p, int nb1, int nb2, h16x8 (&bh)[N
                 sc->fout[16 * (NT - 1) + 2 * i] = fmaf(pacc2[2 * i], LO_INV, pacc1[2 * i]);
                 sc->fout[16 * (NT - 1) + 2 * i + 1] = fmaf(pacc2[2 * i + 1], LO_INV, pacc1[2 * i + 1]);
             } else
-            epi_pair_u<RELU>(pacc1, pacc2, i, oh[2 * (NT - 1) + (i >> 2)], ol[2 * (NT - 1) + (i >> 2)]);
+            epi_pair_u<RELU>(pacc1, pacc2, i, oh[2 * (NT - 1) + (i >> 2)], ol[2 * (NT - 1) + (i >> 2)], p.sat);
         }
         if constexpr (sv_fwd(SAVE)) {
 #pragma unroll
@@ -828,7 +856,7 @@ __device__ __forceinline__ void layer16x2(Pipe& p, unsigned stash_per_wave, int 
                     for (int j = 0; j < 16; ++j)
                         if ((j * NK) / 16 == ks) {
                             const int g = j >> 3, i = j & 7;
-                            epi_pair_u<RELU>(pacc1[g], pacc2[g], i, oh[g][2 * (t - 1) + (i >> 2)], ol[g][2 * (t - 1) + (i >> 2)]);
+                            epi_pair_u<RELU>(pacc1[g], pacc2[g], i, oh[g][2 * (t - 1) + (i >> 2)], ol[g][2 * (t - 1) + (i >> 2)], p.sat);
                             asm volatile("" : "+v"(oh[g][2 * (t - 1) + (i >> 2)]), "+v"(ol[g][2 * (t - 1) + (i >> 2)]));
                         }
                 }
@@ -864,7 +892,7 @@ __device__ __forceinline__ void layer16x2(Pipe& p, unsigned stash_per_wave, int 
         } else {
 #pragma unroll
             for (int i = 0; i < 8; ++i)
-                epi_pair_u<RELU>(pacc1[g], pacc2[g], i, oh[g][2 * (NT - 1) + (i >> 2)], ol[g][2 * (NT - 1) + (i >> 2)]);
+                epi_pair_u<RELU>(pacc1[g], pacc2[g], i, oh[g][2 * (NT - 1) + (i >> 2)], ol[g][2 * (NT - 1) + (i >> 2)], p.sat);
         }
     }
 }
@@ -880,6 +908,7 @@ __device__ __forceinline__ Pipe pipe_start(const char* packed, int64_t bias_img_
     p.slab_bytes = slab_bytes;
     p.ph = 0;
     p.bias_off = 0;
+    p.sat = 0ull;
 #ifdef HNRF_STAMP
     p.t_last = __builtin_readcyclecounter();
     p.sum_k = p.sum_b = 0;
@@ -989,6 +1018,7 @@ __global__ __launch_bounds__(256) void canonical_f16x3_kernel(const float* __res
     const float hs = ob[8];
     if (h == 0 && slot < P)
         raw[sample] = make_float4(fmaf(last[0], hs, ob[0]), fmaf(last[1], hs, ob[1]), fmaf(last[2], hs, ob[2]), fmaf(last[3], hs, ob[3]));
+    if constexpr (SAVE == SV_NONE) raise_f16_range(packed, CNL16_STATUS, p.sat);
 #ifdef HNRF_STAMP
     if (threadIdx.x == 0 && blockIdx.x < 4096) {   // stamps leave through a buffer nothing else reads
         const unsigned long long te = __builtin_readcyclecounter();
@@ -1174,6 +1204,7 @@ __global__ __launch_bounds__(256) void nonrigid_f16x3_x2_kernel(const float* __r
             }
         }
     }
+    raise_f16_range(packed, NR16_STATUS, p.sat);
 }
 
 // ============================================================================ dX chain, split-f16
@@ -1538,6 +1569,8 @@ static int launch_pack16(const PackLayer16* ds, int count, const float* cond, ch
 
 size_t canonical16_bytes() { return (size_t)CNL16_BYTES; }
 size_t nonrigid16_bytes() { return (size_t)NR16_BYTES; }
+size_t canonical16_status_offset() { return (size_t)CNL16_STATUS; }
+size_t nonrigid16_status_offset() { return (size_t)NR16_STATUS; }
 
 int canonical16_pack(const float* const* w, const float* const* b, void* packed, hipStream_t st) {
     char* out = (char*)packed;

@@ -408,6 +408,11 @@ def check_config_is_built(config):
                                   '(SURVEY.md section 2.1): ' + '; '.join(bad))
 
 
+class ActivationRangeError(RuntimeError):
+    """A hidden activation of one of the two MLPs left the range of the split-f16 arithmetic (|x| >= 6e4; the kernels
+    clamp at 65504): the frames rendered with these weights in mlp_mode 'f16x3' are not the network's output."""
+
+
 class Network(nn.Module):
     def __init__(self):
         super().__init__()
@@ -430,6 +435,11 @@ class Network(nn.Module):
                 mlp_depth=cfg.pose_decoder.mlp_depth, total_bones=cfg.total_bones)
         self._cnl_pack = None     # (key, packed image)
         self._nr_pack_buf = None
+        # f16-range guard of inference (the training side has autograd.OperandRangeGuard): pinned copy of the two
+        # images' status words, the event behind it, and the mode forced after a hit with cfg.amd.on_f16_range = 'f32'
+        self._range_watch = None
+        self._forced_mode = None
+        self.f16_range_hits = 0
         self._vol_cache = None    # (key, priors, volume)
         self._workspace = None
         # set by train.Trainer when world_size > 1: dist.GradientSync whose volume_hook averages the weight-volume
@@ -446,7 +456,56 @@ class Network(nn.Module):
 
     # packed-weight caches ----------------------------------------------------
     def _mlp_mode(self):
-        return amd_option('mlp_mode', 'f16x3')
+        return self._forced_mode or amd_option('mlp_mode', 'f16x3')
+
+    # f16-range guard ---------------------------------------------------------
+    def _watch_f16_range(self, cnl_packed, nr_packed, mode):
+        """Called after a frame's inference kernels are queued: looks at the status words copied after the PREVIOUS
+        frame (no synchronisation: the copy is long done), then queues this frame's copy -- behind the kernels in stream
+        order, in front of the next frame's pack, which zeroes the non-rigid image's word."""
+        self.check_f16_range(wait=False)
+        words = [w for w in (ops.status_word(cnl_packed, 'canonical', mode),
+                             None if nr_packed is None else ops.status_word(nr_packed, 'nonrigid', mode)) if w is not None]
+        if not words:
+            return
+        if self._range_watch is None:
+            self._range_watch = {'host': torch.zeros(2, dtype=torch.int32).pin_memory(), 'event': None}
+        host = self._range_watch['host']
+        for i, w in enumerate(words):
+            host[i:i + 1].copy_(w, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        self._range_watch['event'] = ev
+
+    def check_f16_range(self, wait=True):
+        """Act on the status words of the last watched frame (``wait``: block until their copy has landed -- render
+        loops call this once after their last frame).  Returns True when the range was left."""
+        w = self._range_watch
+        if w is None or w['event'] is None:
+            return False
+        if not w['event'].query():
+            if not wait:
+                return False
+            w['event'].synchronize()
+        w['event'] = None
+        cnl_hit, nr_hit = int(w['host'][0]), int(w['host'][1])
+        w['host'].zero_()
+        if not (cnl_hit or nr_hit):
+            return False
+        self.f16_range_hits += 1
+        self._cnl_pack = None                                   # (a fresh pack clears the canonical image's word)
+        policy = amd_option('on_f16_range', 'raise')
+        msg = ("a hidden activation of the %s MLP reached the f16 range (|x| >= 6e4) in mlp_mode 'f16x3': the frames "
+               "rendered with these weights are clamped, not the network's output; render with cfg.amd.mlp_mode = 'f32'"
+               % (' and the '.join(n for n, h in (('canonical', cnl_hit), ('non-rigid', nr_hit)) if h)))
+        if policy == 'ignore':
+            return True
+        if policy == 'f32':
+            import warnings
+            warnings.warn(msg + " -- switching this network to 'f32' (cfg.amd.on_f16_range = 'f32')")
+            self._forced_mode = 'f32'
+            return True
+        raise ActivationRangeError(msg)
 
     def _canonical_packed(self):
         lin = self.cnl_mlp.module.linears()
@@ -553,6 +612,8 @@ class Network(nn.Module):
                 cnl_packed, bg, S, int(cfg.chunk), mode, diagnostics=diag,
                 cull_eps=0.0 if diag else float(amd_option('cull_eps', 0.0)), workspace=self._workspace,
                 overlap=bool(amd_option('overlap_warp', False)), mlp_event_log=self.mlp_event_log)
+            if mode == 'f16x3':
+                self._watch_f16_range(cnl_packed, nr_packed, mode)
         else:
             chunks = []
             for i in range(0, N, int(cfg.chunk)):                          # network.py:333
@@ -568,6 +629,8 @@ class Network(nn.Module):
                                                 motion_Rs, motion_Ts, vol, bbox_min, bbox_scale, hann_w,
                                                 nr_packed, cnl_packed, bg, S, mode, diag, None))
             out = {k: (torch.cat([c[k] for c in chunks], 0) if len(chunks) > 1 else chunks[0][k]) for k in chunks[0]}
+            if not train_path and mode == 'f16x3':
+                self._watch_f16_range(cnl_packed, nr_packed, mode)
         lead = list(rays_shape[:-1])
         return {k: v.reshape(lead + list(v.shape[1:])) for k, v in out.items()}
 

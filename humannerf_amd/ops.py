@@ -119,6 +119,21 @@ def canonical_pack(weights, biases, mode='f32', out=None):
     return out
 
 
+def status_word(packed, which, mode):
+    """View (1 int32 element, on the device) of a packed image's status word, or None when ``mode`` has none
+    (hnrf_canonical_status_offset / hnrf_nonrigid_status_offset): the f16x3 inference kernels OR
+    STATUS_F16_RANGE into it when an activation came within reach of the f16 clamp."""
+    lib = _lib.load()
+    off = (lib.hnrf_canonical_status_offset if which == 'canonical' else lib.hnrf_nonrigid_status_offset)(MLP_MODES[mode])
+    if off == 0:
+        return None
+    assert off % 4 == 0 and packed.dtype == torch.float32
+    return packed.view(torch.int32)[off // 4:off // 4 + 1]
+
+
+STATUS_F16_RANGE = 1
+
+
 def canonical(xyz, packed, mode='f32'):
     """K3 (fourier.py:9-38 + mlp_rgb_sigma.py:132-198).  xyz (...,3) -> raw (...,4)."""
     lib = _lib.load()

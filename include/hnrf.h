@@ -47,6 +47,20 @@ extern "C" {
 int         hnrf_abi_version(void);
 const char* hnrf_last_error(void);
 
+/* ---- f16-range guard of the HNRF_MLP_F16X3 inference kernels ------------------
+ * The split v = hi + lo only holds below 65504: the kernels clamp post-ReLU activations there, so a checkpoint whose
+ * hidden activations leave the f16 range would render a wrong image without any error (the reference's fp32 nn.Linear
+ * chains, mlp_rgb_sigma.py:163-198 / mlp_offset.py:74-84, have no such limit).  Every packed image therefore carries a
+ * STATUS WORD (uint32 at byte offset hnrf_*_status_offset(mode) of the caller's `packed` buffer; zeroed by every
+ * hnrf_*_pack): hnrf_canonical_fwd / hnrf_nonrigid_fwd, their sparse forms and the hnrf_render_* entries OR
+ * HNRF_STATUS_F16_RANGE into it when any activation reached 6e4.  This is the one place where a forward call
+ * writes into `packed`.  The caller reads the word when it likes (no call synchronises) and re-renders with
+ * HNRF_MLP_F32, which has no such limit (offset 0 = the mode has no status word).  Training has its own guard on
+ * the saved activations (humannerf_amd/autograd.py OperandRangeGuard). */
+#define HNRF_STATUS_F16_RANGE 1u
+size_t hnrf_canonical_status_offset(int mode);
+size_t hnrf_nonrigid_status_offset(int mode);
+
 /* ---- K1: z-sampling + inverse-LBS warp ------------------------------------
  * Replaces Network._get_samples_along_ray / _stratified_sampling
  * (network.py:455-471), pts = o + d*z (network.py:499) and

@@ -75,6 +75,7 @@ def test_network_matches_reference_golden(case, mode, gpu_net, golden_case, seed
             for k in HEAD:                                  # the dense cases differ in the sigma row of the head
                 sd[k].copy_(torch.from_numpy(state[k]))
             out = gpu_net(**frame_to_gpu(frame), iter_val=m['iter_val'], **kw)
+        assert gpu_net.check_f16_range(wait=True) is False      # no golden case comes near the f16 clamp
     finally:
         with torch.no_grad():
             for k in HEAD:
@@ -112,6 +113,51 @@ def test_network_matches_reference_golden(case, mode, gpu_net, golden_case, seed
     sel = g['cnl_weight'] > 1e-4
     same = np.abs(out['cnl_xyz'][sel] - g['cnl_xyz'][sel]).max(axis=-1) < 1e-3
     assert same.mean() > 0.97
+
+
+@pytest.mark.parametrize('which', ['cnl_mlp.module.pts_linears.2.weight', 'non_rigid_mlp.module.block_mlps.2.weight'])
+@pytest.mark.parametrize('diag', [True, False])
+def test_f16_range_guard_of_inference(which, diag, gpu_net, golden_frame, seeded_params):
+    """inference in the default 'f16x3' arithmetic clamps hidden activations at 65504 -- silently,
+    until now.  A hidden layer scaled x 3000 (activations ~1e5) must raise one frame late (or at the loop's closing
+    check) through the status word of the packed image, in both MLPs and on both output paths; with
+    cfg.amd.on_f16_range = 'f32' the network switches itself to the exact kernels, whose result is then the fp32 CPU
+    oracle's; the seeded weights never trip it (asserted in every golden case above); 'f32' mode has no such limit."""
+    from humannerf_amd.config import cfg
+    from humannerf_amd.network import ActivationRangeError
+    from oracle import oracle
+    cfg.perturb, cfg.N_samples, cfg.amd.mlp_mode, cfg.amd.diagnostics = 0., 128, 'f16x3', diag
+    data = frame_to_gpu(golden_frame)
+    sd = gpu_net.state_dict()
+    try:
+        with torch.no_grad():
+            sd[which].mul_(3000.0)
+            gpu_net(**data, iter_val=1e7)                        # queued: the verdict arrives behind the frame
+            with pytest.raises(ActivationRangeError, match='canonical' if which.startswith('cnl') else 'non-rigid'):
+                gpu_net.check_f16_range(wait=True)
+            assert gpu_net.f16_range_hits >= 1
+            # one frame late inside a loop: the second call looks at the first frame's word
+            gpu_net(**data, iter_val=1e7)
+            torch.cuda.synchronize()
+            with pytest.raises(ActivationRangeError):
+                gpu_net(**data, iter_val=1e7)
+            # fall-back policy: warn, switch to the exact kernels, which then agree with the CPU oracle on these weights
+            cfg.amd.on_f16_range = 'f32'
+            gpu_net._range_watch = None
+            gpu_net(**data, iter_val=1e7)
+            with pytest.warns(UserWarning, match="switching this network to 'f32'"):
+                assert gpu_net.check_f16_range(wait=True) is True
+            assert gpu_net._mlp_mode() == 'f32'
+            out = gpu_net(**data, iter_val=1e7)
+            assert gpu_net.check_f16_range(wait=True) is False
+            state = {k: v.detach().cpu().numpy() for k, v in sd.items()}
+            ref = oracle.render(state, golden_frame, iter_val=1e7, N_samples=128)
+            assert float((out['alpha'].cpu() - ref['alpha']).abs().max()) <= 1e-3      # (activations of 1e5: fp32 noise scales with them)
+    finally:
+        with torch.no_grad():
+            sd[which].copy_(torch.from_numpy(seeded_params[which]))
+        cfg.amd.on_f16_range, cfg.amd.diagnostics, cfg.perturb = 'raise', True, 1.0
+        gpu_net._forced_mode, gpu_net._range_watch, gpu_net._cnl_pack = None, None, None
 
 
 def test_lean_path_equals_diagnostic_path(gpu_net, golden_frame):
