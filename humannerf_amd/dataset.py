@@ -217,16 +217,21 @@ class Subject:
         return out
 
     # -- frame kinds ------------------------------------------------------------------------------------------
-    def movement_frame(self, idx, bgcolor=None, host_rays=False, image_size=None, load_image=False):
+    def movement_frame(self, idx, bgcolor=None, host_rays=False, image_size=None, load_image=False, device=None):
         """What the train dataset yields in ray_shoot_mode 'image' (movement / progress renders,
         train.py:481-755): the frame's own camera and pose.  ``image_size`` (H, W) is needed when the image is
-        not loaded (camera-only rendering)."""
+        not loaded (camera-only rendering).  ``device`` (a GPU): the image goes through load_image_device -- the PNGs
+        are decoded here, undistortion / composite / resize run on the device and ``raw_rgbs`` is a tensor there."""
         name = self.framelist[idx]
         info, cam = self.mesh_infos[name], self.cameras[name]
         bg = np.array(cfg.bgcolor if bgcolor is None else bgcolor, dtype='float32')
         out = {'frame_name': name, 'bgcolor': bg}
         img = None
-        if load_image:
+        if load_image and device is not None and str(device).startswith('cuda') and not host_rays:
+            img, _, flag = self.load_image_device(name, bg, device)
+            H, W = int(img.shape[0]), int(img.shape[1])
+            out['resize_parity'] = flag
+        elif load_image:
             img, alpha, flag = self.load_image(name, bg)
             img = (img / 255.).astype('float32')
             H, W = img.shape[:2]

@@ -439,7 +439,7 @@ class Network(nn.Module):
         # images' status words, the event behind it, and the mode forced after a hit with cfg.amd.on_f16_range = 'f32'
         self._range_watch = None
         self._forced_mode = None
-        self.f16_range_hits = 0
+        self.f16_range_hits = self.f16_range_watched = self.f16_range_checked = 0
         self._vol_cache = None    # (key, priors, volume)
         self._workspace = None
         # set by train.Trainer when world_size > 1: dist.GradientSync whose volume_hook averages the weight-volume
@@ -460,36 +460,47 @@ class Network(nn.Module):
 
     # f16-range guard ---------------------------------------------------------
     def _watch_f16_range(self, cnl_packed, nr_packed, mode):
-        """Called after a frame's inference kernels are queued: looks at the status words copied after the PREVIOUS
-        frame (no synchronisation: the copy is long done), then queues this frame's copy -- behind the kernels in stream
-        order, in front of the next frame's pack, which zeroes the non-rigid image's word."""
-        self.check_f16_range(wait=False)
-        words = [w for w in (ops.status_word(cnl_packed, 'canonical', mode),
-                             None if nr_packed is None else ops.status_word(nr_packed, 'nonrigid', mode)) if w is not None]
-        if not words:
+        """Called after a frame's inference kernels are queued: copies the two images' status words into a pinned slot
+        -- behind the kernels in stream order, in front of the next frame's pack, which zeroes the non-rigid image's
+        word -- and notes the event behind the copy.  Nothing waits: check_f16_range looks at the slots whose copy has
+        landed (Network.forward does at its start, i.e. one frame late when the host keeps up with the GPU)."""
+        words = [ops.status_word(cnl_packed, 'canonical', mode),
+                 None if nr_packed is None else ops.status_word(nr_packed, 'nonrigid', mode)]
+        if words[0] is None and words[1] is None:
             return
         if self._range_watch is None:
-            self._range_watch = {'host': torch.zeros(2, dtype=torch.int32).pin_memory(), 'event': None}
-        host = self._range_watch['host']
-        for i, w in enumerate(words):
-            host[i:i + 1].copy_(w, non_blocking=True)
+            import collections
+            self._range_watch = {'pending': collections.deque(), 'free': []}
+        w = self._range_watch
+        host = w['free'].pop() if w['free'] else torch.zeros(2, dtype=torch.int32).pin_memory()
+        host.zero_()
+        for i, word in enumerate(words):
+            if word is not None:
+                host[i:i + 1].copy_(word, non_blocking=True)
         ev = torch.cuda.Event()
         ev.record()
-        self._range_watch['event'] = ev
+        w['pending'].append((host, ev))
+        self.f16_range_watched += 1
 
     def check_f16_range(self, wait=True):
-        """Act on the status words of the last watched frame (``wait``: block until their copy has landed -- render
-        loops call this once after their last frame).  Returns True when the range was left."""
+        """Act on the status words of the watched frames whose copies have landed (``wait``: of all watched frames,
+        blocking -- render loops call this once after their last frame).  ``f16_range_checked`` counts the frames whose
+        verdict is known.  Returns True when one of them left the range."""
         w = self._range_watch
-        if w is None or w['event'] is None:
+        if w is None:
             return False
-        if not w['event'].query():
-            if not wait:
-                return False
-            w['event'].synchronize()
-        w['event'] = None
-        cnl_hit, nr_hit = int(w['host'][0]), int(w['host'][1])
-        w['host'].zero_()
+        cnl_hit = nr_hit = 0
+        while w['pending']:
+            host, ev = w['pending'][0]
+            if not ev.query():
+                if not wait:
+                    break
+                ev.synchronize()
+            w['pending'].popleft()
+            self.f16_range_checked += 1
+            cnl_hit |= int(host[0])
+            nr_hit |= int(host[1])
+            w['free'].append(host)
         if not (cnl_hit or nr_hit):
             return False
         self.f16_range_hits += 1
@@ -549,6 +560,8 @@ class Network(nn.Module):
         stratified-sampling uniforms (parity tests); unknown kwargs are ignored
         like the reference's **kwargs."""
         train_path = torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
+        if self._range_watch is not None and self._range_watch['pending']:
+            self.check_f16_range(wait=False)       # the previous frames' f16-range verdicts (may switch the mode, or raise)
         iter_val = float(iter_val)
         dev = dst_Rs.device
         f32 = lambda t: t.to(dtype=torch.float32)

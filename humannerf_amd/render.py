@@ -67,23 +67,27 @@ def tile_images(images, imgs_per_row=4):
     return np.concatenate(rows, axis=0)
 
 
-def unpack_to_image(width, height, ray_mask, bgcolor, rgb, alpha, truth=None):
+def unpack_to_image(width, height, ray_mask, bgcolor, rgb, alpha, truth=None, ray_index=None):
     """Device-side restatement of run.py:48-65.  ``bgcolor`` in 0..1 like the reference's call sites pass it
     (run.py:127-131); ``rgb`` (N, 3), ``alpha`` (N,), optional ``truth`` (N, 3) for the rays selected by ``ray_mask``
     (H*W,) bool.  Returns (rgb uint8 (H,W,3), alpha uint8 (H,W,3), truth uint8 (H,W,3)); without ``truth`` the third
-    entry is the float32 (H*W, 3) background plane, as in the reference."""
+    entry is the float32 (H*W, 3) background plane, as in the reference.
+    ``ray_index`` (N,) int64 = the positions where ``ray_mask`` is set: with it the scatter is an index_copy and nothing
+    here waits for the device (a boolean-mask assignment counts the set bits on the host: one synchronisation per
+    image, which is what kept the frame loop from running ahead of the GPU)."""
     dev = rgb.device
     bg = torch.as_tensor(bgcolor, dtype=torch.float32, device=dev).reshape(1, 3)
-    ray_mask = torch.as_tensor(ray_mask, device=dev)
+    if ray_index is None:
+        ray_index = torch.nonzero(torch.as_tensor(ray_mask, device=dev).reshape(-1)).reshape(-1)
     img = bg.repeat(height * width, 1)
-    img[ray_mask] = rgb.to(torch.float32)
+    img.index_copy_(0, ray_index, rgb.to(torch.float32))
     rgb8 = to_8b_image(img).reshape(height, width, 3)
     truth_img = bg.repeat(height * width, 1)
     if truth is not None:
-        truth_img[ray_mask] = torch.as_tensor(truth, dtype=torch.float32, device=dev)
+        truth_img.index_copy_(0, ray_index, torch.as_tensor(truth, dtype=torch.float32, device=dev))
         truth_img = to_8b_image(truth_img).reshape(height, width, 3)
     amap = torch.zeros(height * width, dtype=torch.float32, device=dev)
-    amap[ray_mask] = alpha.to(torch.float32)
+    amap.index_copy_(0, ray_index, alpha.to(torch.float32))
     a8 = to_8b3ch_image(amap.reshape(height, width)).contiguous()
     return rgb8, a8, truth_img
 
@@ -282,7 +286,118 @@ class _PinnedPool:
         self.free[tuple(t.shape)].append(t)
 
 
-def render_frames(network, frames, rank=0, world=1, device=None, on_image=None, show_truth=False):
+_FRAME_KEYS = ('dst_Rs', 'dst_Ts', 'cnl_gtfms', 'dst_posevec', 'cnl_bbox_min_xyz', 'cnl_bbox_scale_xyz', 'bgcolor')
+
+
+class FramePrefetcher:
+    """The DataLoader of the reference's render loops (create_dataset.py:81-85: worker processes build the per-frame
+    dicts while ``run.py:240-300`` renders) for one process per GPU: a worker thread walks this rank's frame indices
+    ``depth`` frames ahead of the renderer and, per frame,
+      * builds ``frames[idx]`` (the host part: SMPL helpers, PNG decoding for frames that carry their image),
+      * uploads it through pinned memory on a SIDE stream,
+      * runs everything that needs a device round trip there as well: ray generation for camera-only frames
+        (hnrf_gen_rays reads the ray count back), image undistortion / composite / resize of frames loaded by
+        ``Subject.load_image_device``, the index list of the hit pixels and the truth pixels under it,
+    and hands over device tensors plus the event that marks them ready.  The render stream only ever waits for that
+    event: no host synchronisation is left in the loop, so the GPU renders frame n while the host prepares n+1.."""
+
+    def __init__(self, frames, indices, device, show_truth=False, depth=2):
+        self.frames, self.indices, self.device, self.show_truth = frames, list(indices), device, show_truth
+        self.on_gpu = device.type == 'cuda'
+        self._resident = {}
+        self._q = queue.Queue(maxsize=max(1, depth))
+        self._stop = False
+        if self.on_gpu:
+            self.stream = torch.cuda.Stream(device=device)
+            self._thread = threading.Thread(target=self._work, daemon=True)
+            self._thread.start()
+
+    # -- one frame ------------------------------------------------------------------------------------------
+    def _up(self, v):
+        if torch.is_tensor(v):
+            return v.to(self.device, non_blocking=True)
+        t = torch.as_tensor(np.ascontiguousarray(v) if isinstance(v, np.ndarray) else v)
+        if self.on_gpu and t.numel() > 0:
+            return t.pin_memory().to(self.device, non_blocking=True)
+        return t.to(self.device)
+
+    def _priors(self, pri):
+        # per-subject constant: keep it on the device while the host copy is unchanged, so that the network's
+        # weight-volume cache hits by identity (no per-frame comparison / synchronisation)
+        hit = self._resident.get('priors')
+        if hit is not None and (hit[0] is pri or (isinstance(pri, np.ndarray) and isinstance(hit[0], np.ndarray)
+                                                  and hit[0].shape == pri.shape and np.array_equal(hit[0], pri))):
+            return hit[1]
+        t = self._up(pri)
+        self._resident['priors'] = (pri, t)
+        return t
+
+    def build(self, idx):
+        fr = self.frames[idx]
+        if 'rays' not in fr:
+            from . import ops
+            fr = dict(fr)
+            # rays are clipped against the POSED skeleton's bbox (freeview.py:226; dataset.Subject puts it in
+            # ray_bbox_*); the synthetic frames of scene.py pose nothing and use the canonical one
+            fr.update(ops.gen_rays(fr['K'], fr['E'], fr.get('ray_bbox_min_xyz', fr['cnl_bbox_min_xyz']),
+                                   fr.get('ray_bbox_max_xyz', fr['cnl_bbox_max_xyz']),
+                                   int(fr['img_height']), int(fr['img_width']), device=self.device))
+        data = {k: self._up(fr[k]) for k in ('rays', 'near', 'far') + _FRAME_KEYS}
+        data['motion_weights_priors'] = self._priors(fr['motion_weights_priors'])
+        mask = self._up(fr['ray_mask']).reshape(-1)
+        index = torch.nonzero(mask).reshape(-1)                          # (the one read-back of the frame: on this stream)
+        truth = None
+        if self.show_truth and fr.get('target_rgbs', None) is not None:
+            truth = self._up(fr['target_rgbs'])
+        elif self.show_truth and fr.get('raw_rgbs', None) is not None:   # whole image (0..1): the pixels the rays hit
+            truth = self._up(fr['raw_rgbs']).reshape(-1, 3).index_select(0, index)
+        return {'idx': idx, 'data': data, 'ray_index': index, 'truth': truth,
+                'W': int(fr['img_width']), 'H': int(fr['img_height'])}
+
+    def _work(self):
+        try:
+            with torch.cuda.device(self.device), torch.cuda.stream(self.stream):
+                for idx in self.indices:
+                    if self._stop:
+                        return
+                    item = self.build(idx)
+                    ev = torch.cuda.Event()
+                    ev.record(self.stream)
+                    item['event'] = ev
+                    self._q.put(item)
+            self._q.put(None)
+        except BaseException as e:                                       # surfaced by the consumer
+            self._q.put(e)
+
+    def __iter__(self):
+        if not self.on_gpu:
+            for idx in self.indices:
+                yield self.build(idx)
+            return
+        main = torch.cuda.current_stream(self.device)
+        while True:
+            item = self._q.get()
+            if item is None:
+                return
+            if isinstance(item, BaseException):
+                raise item
+            main.wait_event(item['event'])
+            for t in list(item['data'].values()) + [item['ray_index'], item['truth']]:
+                if torch.is_tensor(t):
+                    t.record_stream(main)                                # allocated on the side stream, consumed here
+            yield item
+
+    def close(self):
+        self._stop = True
+        if self.on_gpu:
+            while self._thread.is_alive():                               # unblock a worker waiting on a full queue
+                try:
+                    self._q.get(timeout=0.05)
+                except queue.Empty:
+                    pass
+
+
+def render_frames(network, frames, rank=0, world=1, device=None, on_image=None, show_truth=False, prefetch=2):
     """Render ``frames`` (sequence of per-frame input dicts, numpy or tensors) frame-sharded.
 
     Returns {frame_idx: uint8 rgb image on the host} for this rank's frames.  ``on_image(idx, rgb8, alpha8[,
@@ -293,23 +408,27 @@ def render_frames(network, frames, rank=0, world=1, device=None, on_image=None, 
     A frame may carry its camera instead of precomputed rays -- ``K`` (3,3), ``E`` (4,4), ``cnl_bbox_max_xyz`` next to
     ``img_width`` / ``img_height`` and no ``rays``: the rays, near/far and ray_mask are then generated on the
     device (ops.gen_rays = get_rays_from_KRT + rays_intersect_3d_bbox, freeview.py:220-230) instead of the
-    per-frame numpy pass and the 32 B/ray upload."""
+    per-frame numpy pass and the 32 B/ray upload.
+
+    Frames are assembled ``prefetch`` ahead by ``FramePrefetcher`` (host work and every device read-back on a side
+    stream); finished images leave through pinned buffers on a copy stream and are handed to ``on_image`` one frame
+    late at the earliest -- after the next frame's forward has looked at this frame's f16-range verdict
+    (Network.check_f16_range), so that with ``cfg.amd.on_f16_range = 'f32'`` a frame rendered out of range is
+    rendered again with the exact kernels before anybody sees it."""
     device = device or next(network.parameters()).device
     network.eval()
     quiet_gc()
-    keys = ('rays', 'near', 'far', 'dst_Rs', 'dst_Ts', 'cnl_gtfms', 'motion_weights_priors', 'dst_posevec',
-            'cnl_bbox_min_xyz', 'cnl_bbox_scale_xyz', 'bgcolor')
     old = cfg.perturb
     cfg.perturb = 0.                                                     # run.py:71,215
     out = {}
     on_gpu = device.type == 'cuda'
     copy_stream = torch.cuda.Stream(device=device) if on_gpu else None
     pool = _PinnedPool()
-    pending = []
-    resident = {}                                                        # key -> (host array, device tensor)
+    pending = []                                    # [idx, hosts, event, item, watch id]: oldest first
+    guard = hasattr(network, 'check_f16_range')
 
-    def deliver(item):
-        i, hosts, e = item
+    def deliver(entry):
+        i, hosts, e = entry[:3]
         if e is not None:
             e.synchronize()
         arrs = [h.numpy().copy() if on_gpu else h.numpy() for h in hosts]
@@ -320,60 +439,67 @@ def render_frames(network, frames, rank=0, world=1, device=None, on_image=None, 
         if on_image is not None:
             on_image(i, *arrs)
 
+    def render(item):
+        with torch.no_grad():
+            res = network(**item['data'], iter_val=float(cfg.eval_iter))
+        rgb8, a8, t8 = unpack_to_image(item['W'], item['H'], None, item['data']['bgcolor'] / 255., res['rgb'], res['alpha'],
+                                       item['truth'], ray_index=item['ray_index'])
+        imgs = [rgb8, a8] + ([t8] if item['truth'] is not None else [])
+        wid = network.f16_range_watched if guard else 0
+        if not on_gpu:
+            return [item['idx'], [im.cpu() for im in imgs], None, item, wid]
+        copy_stream.wait_stream(torch.cuda.current_stream(device))      # overlap D2H with the next frame
+        hosts = []
+        with torch.cuda.stream(copy_stream):
+            for im in imgs:
+                h = pool.take(im.shape)
+                h.copy_(im, non_blocking=True)
+                im.record_stream(copy_stream)
+                hosts.append(h)
+            ev = torch.cuda.Event()
+            ev.record(copy_stream)
+        return [item['idx'], hosts, ev, item, wid]
+
+    def rerender_pending():
+        """A range hit with cfg.amd.on_f16_range = 'f32' has switched the network to the exact kernels: every frame not
+        yet handed over was rendered with the clamped ones (or has no verdict yet) and is rendered again; frames
+        handed over earlier had their verdict and were fine."""
+        for k, entry in enumerate(pending):
+            if entry[2] is not None:
+                entry[2].synchronize()
+            if on_gpu:
+                for h in entry[1]:
+                    pool.give(h)
+            pending[k] = render(entry[3])
+
+    def verdicts(wait):
+        if guard:
+            hits = network.f16_range_hits
+            network.check_f16_range(wait=wait)
+            if network.f16_range_hits != hits:
+                rerender_pending()
+
+    def known(entry):
+        return not guard or network.f16_range_checked >= entry[4]
+
+    pre = FramePrefetcher(frames, hdist.frame_shard(len(frames), rank, world), device, show_truth=show_truth, depth=prefetch)
     try:
-        for idx in hdist.frame_shard(len(frames), rank, world):
-            fr = frames[idx]
-            if 'rays' not in fr:
-                from . import ops
-                fr = dict(fr)
-                # rays are clipped against the POSED skeleton's bbox (freeview.py:226; dataset.Subject puts it in
-                # ray_bbox_*); the synthetic frames of scene.py pose nothing and use the canonical one
-                fr.update(ops.gen_rays(fr['K'], fr['E'], fr.get('ray_bbox_min_xyz', fr['cnl_bbox_min_xyz']),
-                                       fr.get('ray_bbox_max_xyz', fr['cnl_bbox_max_xyz']),
-                                       int(fr['img_height']), int(fr['img_width']), device=device))
-            data = {k: torch.as_tensor(np.ascontiguousarray(fr[k]) if isinstance(fr[k], np.ndarray) else fr[k]).to(device)
-                    for k in keys if k != 'motion_weights_priors'}
-            # the priors are per-subject constants: keep them on the device while the host copy is unchanged, so
-            # that the network's weight-volume cache hits by identity (no per-frame comparison / synchronisation)
-            pri = fr['motion_weights_priors']
-            hit = resident.get('priors')
-            if hit is not None and (hit[0] is pri or (isinstance(pri, np.ndarray) and isinstance(hit[0], np.ndarray)
-                                                      and hit[0].shape == pri.shape and np.array_equal(hit[0], pri))):
-                data['motion_weights_priors'] = hit[1]
-            else:
-                data['motion_weights_priors'] = torch.as_tensor(
-                    np.ascontiguousarray(pri) if isinstance(pri, np.ndarray) else pri).to(device)
-                resident['priors'] = (pri, data['motion_weights_priors'])
-            with torch.no_grad():
-                res = network(**data, iter_val=float(cfg.eval_iter))
-            mask = torch.as_tensor(fr['ray_mask']).to(device)
-            truth = None
-            if show_truth and fr.get('target_rgbs', None) is not None:
-                truth = torch.as_tensor(fr['target_rgbs']).to(device)
-            elif show_truth and fr.get('raw_rgbs', None) is not None:    # whole image (0..1): take the pixels the rays hit
-                truth = torch.as_tensor(np.ascontiguousarray(fr['raw_rgbs'])).to(device).reshape(-1, 3)[mask.reshape(-1)]
-            rgb8, a8, t8 = unpack_to_image(int(fr['img_width']), int(fr['img_height']), mask, data['bgcolor'] / 255.,
-                                           res['rgb'], res['alpha'], truth)
-            imgs = [rgb8, a8] + ([t8] if truth is not None else [])
-            if on_gpu:                                                   # overlap D2H with the next frame
-                copy_stream.wait_stream(torch.cuda.current_stream(device))
-                hosts = []
-                with torch.cuda.stream(copy_stream):
-                    for im in imgs:
-                        h = pool.take(im.shape)
-                        h.copy_(im, non_blocking=True)
-                        im.record_stream(copy_stream)
-                        hosts.append(h)
-                    ev = torch.cuda.Event()
-                    ev.record(copy_stream)
-                pending.append((idx, hosts, ev))
-            else:
-                pending.append((idx, [im.cpu() for im in imgs], None))
-            while pending and (pending[0][2] is None or pending[0][2].query() or len(pending) > 2):
+        for item in pre:
+            hits = network.f16_range_hits if guard else 0
+            pending.append(render(item))                                 # (forward looks at the verdicts that have arrived)
+            if guard and network.f16_range_hits != hits:
+                rerender_pending()
+            # a frame is handed over once its verdict is known and its copy has landed; at most three in flight
+            while pending and (len(pending) > 3 or (known(pending[0]) and (pending[0][2] is None or pending[0][2].query()))):
+                if not known(pending[0]):
+                    verdicts(wait=True)
                 deliver(pending.pop(0))
+        verdicts(wait=True)
+        verdicts(wait=True)                                              # (of the frames a hit had rendered again)
         while pending:
             deliver(pending.pop(0))
     finally:
+        pre.close()
         cfg.perturb = old
     return out
 

@@ -78,9 +78,12 @@ def run_movement(network, subject, render_folder_name='movement', logdir=None, r
     """run.py:212-445.  Frames are loaded with their images (truth panel and metrics), rays come from the device ray
     generator.  Returns the per-rank result dict of the loop; ``['metrics']`` holds this rank's averages."""
     cfg.show_truth = True
+    device = device or next(network.parameters()).device
     n = len(subject) if test_num < 0 else min(test_num, len(subject))
     # camera-only frames: rays come from the device generator, the truth pixels are picked on the device
-    frames = _Frames(n, lambda i: subject.movement_frame(i, load_image=True))
+    # (the prefetcher thread of render_frames builds them: PNG decoding on the host, undistortion / composite / resize on
+    # the device when there is one)
+    frames = _Frames(n, lambda i: subject.movement_frame(i, load_image=True, device=device))
     names = [str(subject.framelist[i]).replace('/', '-') for i in range(n)]
     suffix = '' if world == 1 else '.rank%d' % rank
     mw = render.MetricsWriter(_output_dir(logdir), render_folder_name + suffix, dataset=subject.dataset_path,
@@ -95,8 +98,9 @@ def run_freeview(network, subject, frame_idx=None, total_frames=None, render_fol
     total = int(cfg.get('render_frames', 100)) if total_frames is None else int(total_frames)
     if image_size is None:
         image_size = subject.image_size(subject.framelist_all[frame_idx])
+    # background: cfg.bgcolor, like every non-train dataset the reference builds (create_dataset.py:40)
     frames = _Frames(total, lambda i: subject.freeview_frame(i, total, train_frame_idx=frame_idx, src_type=src_type,
-                                                             image_size=image_size))
+                                                             image_size=image_size, bgcolor=cfg.bgcolor))
     folder = render_folder_name or cfg.get('render_folder_name', '') or 'freeview_%d' % frame_idx
     return _render_loop(network, frames, [None] * total if world == 1 else ['%06d' % i for i in range(total)], folder,
                         logdir, rank, world, device)
@@ -106,7 +110,7 @@ def run_tpose(network, subject, total_frames=None, render_folder_name=None, logd
               image_size=None):
     """run.py:178-183: the turntable of tpose.py with cfg.ignore_non_rigid_motions = True."""
     total = int(cfg.get('render_frames', 100)) if total_frames is None else int(total_frames)
-    frames = _Frames(total, lambda i: subject.tpose_frame(i, total, image_size=image_size))
+    frames = _Frames(total, lambda i: subject.tpose_frame(i, total, image_size=image_size, bgcolor=cfg.bgcolor))
     old = cfg.ignore_non_rigid_motions
     cfg.ignore_non_rigid_motions = True
     try:
