@@ -319,8 +319,10 @@ __device__ __forceinline__ void sat_check_frag(const h16x8& hi, unsigned long lo
                  : "+s"(sflag) : "v"(u), "s"(SAT_HALF << 16), "s"(SAT_HALF) : "vcc");
 }
 __device__ __forceinline__ void raise_f16_range(const char* packed, int64_t off, unsigned long long sflag) {
+    // a plain store, not an atomic OR: the word has this one bit, every writer writes the same value
     if (sflag != 0ull && (threadIdx.x & 63) == 0)
-        atomicOr(reinterpret_cast<unsigned*>(const_cast<char*>(packed) + off), (unsigned)HNRF_STATUS_F16_RANGE);
+        __hip_atomic_store(reinterpret_cast<unsigned*>(const_cast<char*>(packed) + off), (unsigned)HNRF_STATUS_F16_RANGE,
+                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 template <bool RELU>

@@ -46,7 +46,9 @@ class _MeanAllReduceGrad(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g):
-        g = g.contiguous()
+        # a copy: autograd hands the same tensor to every other consumer of this gradient (hooks, retain_grad), a
+        # backward must not write into it (3.3 MB)
+        g = g.clone(memory_format=torch.contiguous_format)
         dist.all_reduce(g, op=dist.ReduceOp.SUM, group=ctx.sync.group)
         return g.div_(ctx.sync.world), None
 
@@ -90,8 +92,21 @@ class GradientSync:
         self.small = [p for n, p in named if 'mweight_vol_decoder' not in n]
         self.buckets = [self.small] if mode == 'volume' else [self.small, self.decoder]
         self.flat = [None] * len(self.buckets)
+        self._flag_cache = [None] * len(self.buckets)      # (has-gradient pattern, device tensor): rebuilt when it changes
         self._pending = []          # [(description, pinned host tensor, event)]
         self.bytes_last_step = 0
+        # Replicas must START equal: the volume mode computes the decoder gradients locally on every rank from the same
+        # averaged volume gradient (bit-identical decoder weights are its premise), and nothing later would bring
+        # differently initialised MLPs together -- a run that does not resume builds each rank's Network from its own
+        # random state (train.train_subject seeds with seed + rank).  Rank 0's parameters and buffers win.
+        if self.active:
+            self.broadcast_state(network)
+
+    def broadcast_state(self, network, src=0):
+        """Every parameter and buffer of ``network`` from rank ``src`` (258 MB over xGMI, once)."""
+        with torch.no_grad():
+            for t in list(network.parameters()) + list(network.buffers()):
+                dist.broadcast(t.data, src=src, group=self.group)
 
     # -- backward-time hook -------------------------------------------------------------------------------
     def volume_hook(self, vol, priors=None):
@@ -127,7 +142,15 @@ class GradientSync:
             flags = flat[n:]
             if len(have) != len(bucket):
                 flat.zero_()
-            flags.copy_(torch.tensor([float(p.grad is not None) for p in bucket]), non_blocking=True)
+            # has-gradient pattern: it changes a handful of times in a run (kick-in iterations), so its device copy is
+            # kept; a fresh pageable host tensor per step would be a stream-synchronising upload per bucket
+            pattern = tuple(p.grad is not None for p in bucket)
+            if self._flag_cache[bi] is None or self._flag_cache[bi][0] != pattern:
+                host = torch.tensor([float(b) for b in pattern])
+                if flat.is_cuda:
+                    host = host.pin_memory()
+                self._flag_cache[bi] = (pattern, host.to(flat.device, non_blocking=True))
+            flags.copy_(self._flag_cache[bi][1])
             src = [p.grad for p in have]
             dst = [v for v, p in zip(views, bucket) if p.grad is not None]
             torch._foreach_copy_(dst, src)

@@ -18,6 +18,7 @@ an image to be written.
 import os
 import queue
 import threading
+import time
 from collections import defaultdict
 
 import numpy as np
@@ -307,6 +308,7 @@ class FramePrefetcher:
         self._resident = {}
         self._q = queue.Queue(maxsize=max(1, depth))
         self._stop = False
+        self.build_s, self.wait_s = [], []          # per frame: worker time to build it / time the renderer waited for it
         if self.on_gpu:
             self.stream = torch.cuda.Stream(device=device)
             self._thread = threading.Thread(target=self._work, daemon=True)
@@ -360,7 +362,9 @@ class FramePrefetcher:
                 for idx in self.indices:
                     if self._stop:
                         return
+                    t0 = time.perf_counter()
                     item = self.build(idx)
+                    self.build_s.append(time.perf_counter() - t0)
                     ev = torch.cuda.Event()
                     ev.record(self.stream)
                     item['event'] = ev
@@ -376,7 +380,9 @@ class FramePrefetcher:
             return
         main = torch.cuda.current_stream(self.device)
         while True:
+            t0 = time.perf_counter()
             item = self._q.get()
+            self.wait_s.append(time.perf_counter() - t0)
             if item is None:
                 return
             if isinstance(item, BaseException):
@@ -501,6 +507,8 @@ def render_frames(network, frames, rank=0, world=1, device=None, on_image=None, 
     finally:
         pre.close()
         cfg.perturb = old
+        render_frames.last_prefetch = {'build_ms': [round(t * 1e3, 2) for t in pre.build_s],
+                                       'wait_ms': [round(t * 1e3, 2) for t in pre.wait_s]}
     return out
 
 

@@ -50,3 +50,6 @@ print('%s: %d frames, %.0f rays per frame; pure render %.2f ms per frame; run_mo
       'loop / pure = %.3f' % ('lens (1024^2 PNGs, distortion, scale 0.5)' if lens else 'plain (512^2 PNGs)', n, rays,
                               pure * 1e3, loop * 1e3, 1 / loop, loop / pure), flush=True)
 print('psnr', res['metrics'])
+from humannerf_amd import render
+lp = render.render_frames.last_prefetch
+print('prefetch: build ms median %.1f max %.1f; renderer waited ms median %.2f max %.1f' % (np.median(lp['build_ms']), max(lp['build_ms']), np.median(lp['wait_ms']), max(lp['wait_ms'])))

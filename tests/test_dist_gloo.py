@@ -25,10 +25,10 @@ def _free_port():
 class _Toy(torch.nn.Module):
     """mweight_vol_decoder (real, 16^3) + two small parameter sets named like the network's."""
 
-    def __init__(self):
+    def __init__(self, seed=1):
         super().__init__()
         from humannerf_amd.network import MotionWeightVolumeDecoder
-        torch.manual_seed(1)
+        torch.manual_seed(seed)
         self.mweight_vol_decoder = MotionWeightVolumeDecoder(embedding_size=32, volume_size=16, total_bones=24)
         self.cnl_mlp = torch.nn.Linear(6, 4)
         self.pose_decoder = torch.nn.Linear(5, 3)          # gets NO gradient in `loss` when use_pose is False
@@ -151,6 +151,51 @@ def test_volume_mode_detects_rank_dependent_priors():
     """The volume trick needs replicated decoder activations; different priors per rank must raise."""
     _, _, _, err = _run('volume', priors_differ=True)
     assert err is not None and 'priors differ' in err
+
+
+def _worker_seeds(rank, world, port, q):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    torch.set_num_threads(2)
+    from humannerf_amd import dist as hd
+    try:
+        net = _Toy(seed=100 + rank)                       # what train_subject does without a checkpoint: seed + rank
+        before = torch.cat([p.detach().reshape(-1) for p in net.parameters()]).clone()
+        sync = hd.GradientSync(net, world, mode='volume')
+        net.grad_sync = sync
+        opt = torch.optim.Adam(net.parameters(), lr=1e-2)
+        net.loss(_priors(0), seed=10 + rank).backward()
+        sync.reduce()
+        opt.step()
+        sync.finish()
+        after = torch.cat([p.detach().reshape(-1) for p in net.parameters()])
+        q.put((rank, before.numpy().copy(), after.numpy().copy(),
+               torch.cat([p.detach().reshape(-1) for p in _Toy(seed=100).parameters()]).numpy()))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_replicas_start_equal_whatever_the_ranks_initialised():
+    """nothing synchronised the initial parameters -- a run that does not resume builds each rank's network
+    from its own seed, and the volume mode (decoder gradients computed locally from the averaged volume gradient)
+    silently assumes bit-identical decoder weights.  GradientSync now broadcasts rank 0's state on construction:
+    ranks built with DIFFERENT seeds hold rank 0's parameters afterwards and are still equal after an Adam step."""
+    world = 2
+    port = _free_port()
+    ctx = mp.get_context('spawn')
+    q = ctx.SimpleQueue()
+    procs = [ctx.Process(target=_worker_seeds, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get() for _ in range(world)], key=lambda r: r[0])
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    (_, b0, a0, ref0), (_, b1, a1, _) = res
+    assert not (b0 == b1).all()                           # the ranks really started apart
+    assert (a0 == a1).all()                               # ... and are replicas after construction + one step
+    assert (b0 == ref0).all() and not (a0 == b0).all()    # rank 0's initial state won, and the step moved it
 
 
 def test_frame_shard_covers_everything():
