@@ -316,7 +316,8 @@ __device__ __forceinline__ void sat_check_frag(const h16x8& hi, unsigned long lo
     const u16x2 m = __builtin_elementwise_max(__builtin_elementwise_max(a, b), __builtin_elementwise_max(c, d));
     const unsigned u = __builtin_bit_cast(unsigned, m);
     asm volatile("v_cmp_le_u32 vcc, %2, %1\n\ts_or_b64 %0, %0, vcc\n\tv_cmp_le_u16 vcc, %3, %1\n\ts_or_b64 %0, %0, vcc"
-                 : "+s"(sflag) : "v"(u), "s"(SAT_HALF << 16), "s"(SAT_HALF) : "vcc");
+                 : "+s"(sflag) : "v"(u), "s"(SAT_HALF << 16), "s"(SAT_HALF) : "vcc", "scc");   // (s_or_b64 writes SCC: without
+    // the clobber hipcc schedules this between an s_add_u32 / s_addc_u32 pair and a hit adds a carry -- 4 GiB -- to a pointer)
 }
 __device__ __forceinline__ void raise_f16_range(const char* packed, int64_t off, unsigned long long sflag) {
     // a plain store, not an atomic OR: the word has this one bit, every writer writes the same value

@@ -16,7 +16,7 @@ for s in (1.0, scale):
     w2[1] = w2[1] * s
     packed = ops.canonical_pack(w2, bs, 'f16x3')
     word = ops.status_word(packed, 'canonical', 'f16x3')
-    print('canonical scale', s, 'status before', int(word.item()), flush=True)
+    print('canonical scale', s, 'status before', int(word.item()), 'packed %x end %x status %x' % (packed.data_ptr(), packed.data_ptr() + packed.numel() * 4, word.data_ptr()), flush=True)
     raw = ops.canonical(xyz, packed, 'f16x3')
     torch.cuda.synchronize()
     print('  after', int(word.item()), 'raw finite', bool(torch.isfinite(raw).all()), 'max', float(raw.abs().max()), flush=True)
@@ -29,7 +29,8 @@ for s in (1.0, scale):
     w2[1] = w2[1] * s
     packed = ops.nonrigid_pack(w2, nb, cond, 'f16x3')
     word = ops.status_word(packed, 'nonrigid', 'f16x3')
-    print('nonrigid scale', s, 'status before', int(word.item()), flush=True)
+    print('nonrigid scale', s, 'status before', int(word.item()), 'packed %x end %x status %x xyz %x' % (packed.data_ptr(), packed.data_ptr() + packed.numel() * 4, word.data_ptr(), xyz.data_ptr()), flush=True)
     out, _ = ops.nonrigid(xyz, hann, packed, 'f16x3')
+    print('  out %x' % out.data_ptr(), flush=True)
     torch.cuda.synchronize()
     print('  after', int(word.item()), 'finite', bool(torch.isfinite(out).all()), flush=True)
