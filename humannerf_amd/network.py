@@ -482,10 +482,11 @@ class Network(nn.Module):
         w['pending'].append((host, ev))
         self.f16_range_watched += 1
 
-    def check_f16_range(self, wait=True):
+    def check_f16_range(self, wait=True, upto=None):
         """Act on the status words of the watched frames whose copies have landed (``wait``: of all watched frames,
-        blocking -- render loops call this once after their last frame).  ``f16_range_checked`` counts the frames whose
-        verdict is known.  Returns True when one of them left the range."""
+        blocking -- render loops call this once after their last frame; ``upto``: block only until the first ``upto``
+        watched frames have their verdict).  ``f16_range_checked`` counts the frames whose verdict is known.  Returns
+        True when one of them left the range."""
         w = self._range_watch
         if w is None:
             return False
@@ -493,7 +494,7 @@ class Network(nn.Module):
         while w['pending']:
             host, ev = w['pending'][0]
             if not ev.query():
-                if not wait:
+                if not wait or (upto is not None and self.f16_range_checked >= upto):
                     break
                 ev.synchronize()
             w['pending'].popleft()
@@ -544,8 +545,12 @@ class Network(nn.Module):
             # same tensor object as last frame (a driver that keeps the priors resident): no comparison, no host
             # synchronisation; a fresh tensor is compared by value (one device round trip per frame)
             ref, ver = self._vol_cache[3]
-            same = (ref() is priors and ver == priors._version) or torch.equal(self._vol_cache[1], priors)
-            if same:
+            if ref() is priors and ver == priors._version:
+                return self._vol_cache[2]
+            if torch.equal(self._vol_cache[1], priors):
+                # equal by value: remember THIS tensor, so that the frames that follow hit by identity (a render loop
+                # uploads the subject's priors once per loop; comparing every frame blocked the host for a whole frame)
+                self._vol_cache = self._vol_cache[:3] + ((weakref.ref(priors), priors._version),)
                 return self._vol_cache[2]
         vol = self.mweight_vol_decoder(motion_weights_priors=priors[None])[0].contiguous()
         if use_cache:

@@ -302,17 +302,23 @@ class FramePrefetcher:
     and hands over device tensors plus the event that marks them ready.  The render stream only ever waits for that
     event: no host synchronisation is left in the loop, so the GPU renders frame n while the host prepares n+1.."""
 
-    def __init__(self, frames, indices, device, show_truth=False, depth=2):
+    def __init__(self, frames, indices, device, show_truth=False, depth=4, workers=3):
         self.frames, self.indices, self.device, self.show_truth = frames, list(indices), device, show_truth
         self.on_gpu = device.type == 'cuda'
         self._resident = {}
-        self._q = queue.Queue(maxsize=max(1, depth))
-        self._stop = False
+        self._lock = threading.Lock()
+        self._cv = threading.Condition()
+        self._done, self._next_ticket, self._stop = {}, 0, False
+        self._slots = threading.Semaphore(max(1, depth))
         self.build_s, self.wait_s = [], []          # per frame: worker time to build it / time the renderer waited for it
         if self.on_gpu:
-            self.stream = torch.cuda.Stream(device=device)
-            self._thread = threading.Thread(target=self._work, daemon=True)
-            self._thread.start()
+            # several frames are in the making at once: a frame's build is a chain of ~15 small launches and three
+            # read-backs on a side stream, and once the renderer runs ahead (nothing in the loop waits for the GPU) each
+            # of them queues behind a canonical-MLP launch that holds every SIMD for ~9 ms: 150-200 ms of latency per
+            # frame, hidden by building three frames at a time (measured: profiles/r03_movement_loop.txt)
+            self._threads = [threading.Thread(target=self._work, daemon=True) for _ in range(max(1, workers))]
+            for t in self._threads:
+                t.start()
 
     # -- one frame ------------------------------------------------------------------------------------------
     def _up(self, v):
@@ -326,12 +332,22 @@ class FramePrefetcher:
     def _priors(self, pri):
         # per-subject constant: keep it on the device while the host copy is unchanged, so that the network's
         # weight-volume cache hits by identity (no per-frame comparison / synchronisation)
+        with self._lock:
+            return self._priors_locked(pri)
+
+    def _priors_locked(self, pri):
         hit = self._resident.get('priors')
         if hit is not None and (hit[0] is pri or (isinstance(pri, np.ndarray) and isinstance(hit[0], np.ndarray)
                                                   and hit[0].shape == pri.shape and np.array_equal(hit[0], pri))):
+            if hit[2] is not None:                                       # uploaded on another worker's stream
+                torch.cuda.current_stream(self.device).wait_event(hit[2])
             return hit[1]
         t = self._up(pri)
-        self._resident['priors'] = (pri, t)
+        ev = None
+        if self.on_gpu:
+            ev = torch.cuda.Event()
+            ev.record()
+        self._resident['priors'] = (pri, t, ev)
         return t
 
     def build(self, idx):
@@ -357,21 +373,29 @@ class FramePrefetcher:
                 'W': int(fr['img_width']), 'H': int(fr['img_height'])}
 
     def _work(self):
+        stream = torch.cuda.Stream(device=self.device, priority=int(os.environ.get('HNRF_PREFETCH_PRIORITY', '0')))
         try:
-            with torch.cuda.device(self.device), torch.cuda.stream(self.stream):
-                for idx in self.indices:
-                    if self._stop:
-                        return
+            with torch.cuda.device(self.device), torch.cuda.stream(stream):
+                while True:
+                    self._slots.acquire()
+                    with self._lock:
+                        if self._stop or self._next_ticket >= len(self.indices):
+                            return
+                        ticket = self._next_ticket
+                        self._next_ticket += 1
                     t0 = time.perf_counter()
-                    item = self.build(idx)
-                    self.build_s.append(time.perf_counter() - t0)
+                    item = self.build(self.indices[ticket])
                     ev = torch.cuda.Event()
-                    ev.record(self.stream)
+                    ev.record(stream)
                     item['event'] = ev
-                    self._q.put(item)
-            self._q.put(None)
+                    with self._cv:
+                        self.build_s.append(time.perf_counter() - t0)
+                        self._done[ticket] = item
+                        self._cv.notify_all()
         except BaseException as e:                                       # surfaced by the consumer
-            self._q.put(e)
+            with self._cv:
+                self._done['error'] = e
+                self._cv.notify_all()
 
     def __iter__(self):
         if not self.on_gpu:
@@ -379,31 +403,31 @@ class FramePrefetcher:
                 yield self.build(idx)
             return
         main = torch.cuda.current_stream(self.device)
-        while True:
+        for ticket in range(len(self.indices)):
             t0 = time.perf_counter()
-            item = self._q.get()
+            with self._cv:
+                while ticket not in self._done and 'error' not in self._done:
+                    self._cv.wait()
+                if 'error' in self._done:
+                    raise self._done['error']
+                item = self._done.pop(ticket)
             self.wait_s.append(time.perf_counter() - t0)
-            if item is None:
-                return
-            if isinstance(item, BaseException):
-                raise item
+            self._slots.release()
             main.wait_event(item['event'])
             for t in list(item['data'].values()) + [item['ray_index'], item['truth']]:
                 if torch.is_tensor(t):
-                    t.record_stream(main)                                # allocated on the side stream, consumed here
+                    t.record_stream(main)                                # allocated on a side stream, consumed here
             yield item
 
     def close(self):
-        self._stop = True
+        with self._lock:
+            self._stop = True
         if self.on_gpu:
-            while self._thread.is_alive():                               # unblock a worker waiting on a full queue
-                try:
-                    self._q.get(timeout=0.05)
-                except queue.Empty:
-                    pass
+            for _ in self._threads:
+                self._slots.release()
 
 
-def render_frames(network, frames, rank=0, world=1, device=None, on_image=None, show_truth=False, prefetch=2):
+def render_frames(network, frames, rank=0, world=1, device=None, on_image=None, show_truth=False, prefetch=4):
     """Render ``frames`` (sequence of per-frame input dicts, numpy or tensors) frame-sharded.
 
     Returns {frame_idx: uint8 rgb image on the host} for this rank's frames.  ``on_image(idx, rgb8, alpha8[,
@@ -433,8 +457,11 @@ def render_frames(network, frames, rank=0, world=1, device=None, on_image=None, 
     pending = []                                    # [idx, hosts, event, item, watch id]: oldest first
     guard = hasattr(network, 'check_f16_range')
 
+    t_submit, t_wait, t_user = [], [], []           # per frame: launches queued / waiting for the image / on_image
+
     def deliver(entry):
         i, hosts, e = entry[:3]
+        t0 = time.perf_counter()
         if e is not None:
             e.synchronize()
         arrs = [h.numpy().copy() if on_gpu else h.numpy() for h in hosts]
@@ -442,14 +469,25 @@ def render_frames(network, frames, rank=0, world=1, device=None, on_image=None, 
             for h in hosts:
                 pool.give(h)
         out[i] = arrs[0]
+        t1 = time.perf_counter()
         if on_image is not None:
             on_image(i, *arrs)
+        t_wait.append(t1 - t0)
+        t_user.append(time.perf_counter() - t1)
+
+    gpu_ev = []                                     # (start, stop) events around each frame's launches, cfg.amd.loop_timing
 
     def render(item):
+        timing = on_gpu and bool(cfg.get('amd', {}).get('loop_timing', False))
+        if timing:
+            gpu_ev.append((torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)))
+            gpu_ev[-1][0].record()
         with torch.no_grad():
             res = network(**item['data'], iter_val=float(cfg.eval_iter))
         rgb8, a8, t8 = unpack_to_image(item['W'], item['H'], None, item['data']['bgcolor'] / 255., res['rgb'], res['alpha'],
                                        item['truth'], ray_index=item['ray_index'])
+        if timing:
+            gpu_ev[-1][1].record()
         imgs = [rgb8, a8] + ([t8] if item['truth'] is not None else [])
         wid = network.f16_range_watched if guard else 0
         if not on_gpu:
@@ -478,10 +516,10 @@ def render_frames(network, frames, rank=0, world=1, device=None, on_image=None, 
                     pool.give(h)
             pending[k] = render(entry[3])
 
-    def verdicts(wait):
+    def verdicts(wait, upto=None):
         if guard:
             hits = network.f16_range_hits
-            network.check_f16_range(wait=wait)
+            network.check_f16_range(wait=wait, upto=upto)
             if network.f16_range_hits != hits:
                 rerender_pending()
 
@@ -492,13 +530,15 @@ def render_frames(network, frames, rank=0, world=1, device=None, on_image=None, 
     try:
         for item in pre:
             hits = network.f16_range_hits if guard else 0
+            t0 = time.perf_counter()
             pending.append(render(item))                                 # (forward looks at the verdicts that have arrived)
+            t_submit.append(time.perf_counter() - t0)
             if guard and network.f16_range_hits != hits:
                 rerender_pending()
             # a frame is handed over once its verdict is known and its copy has landed; at most three in flight
             while pending and (len(pending) > 3 or (known(pending[0]) and (pending[0][2] is None or pending[0][2].query()))):
                 if not known(pending[0]):
-                    verdicts(wait=True)
+                    verdicts(wait=True, upto=pending[0][4])              # (of the oldest frame only: the queue stays full)
                 deliver(pending.pop(0))
         verdicts(wait=True)
         verdicts(wait=True)                                              # (of the frames a hit had rendered again)
@@ -507,8 +547,14 @@ def render_frames(network, frames, rank=0, world=1, device=None, on_image=None, 
     finally:
         pre.close()
         cfg.perturb = old
-        render_frames.last_prefetch = {'build_ms': [round(t * 1e3, 2) for t in pre.build_s],
-                                       'wait_ms': [round(t * 1e3, 2) for t in pre.wait_s]}
+        ms = lambda ts: [round(t * 1e3, 2) for t in ts]
+        render_frames.last_prefetch = {'build_ms': ms(pre.build_s), 'wait_ms': ms(pre.wait_s), 'submit_ms': ms(t_submit),
+                                       'image_wait_ms': ms(t_wait), 'on_image_ms': ms(t_user)}
+        if gpu_ev:
+            torch.cuda.synchronize(device)
+            render_frames.last_prefetch['gpu_ms'] = [round(a.elapsed_time(b), 2) for a, b in gpu_ev]
+            render_frames.last_prefetch['gpu_gap_ms'] = [round(gpu_ev[i][1].elapsed_time(gpu_ev[i + 1][0]), 2)
+                                                         for i in range(len(gpu_ev) - 1)]
     return out
 
 

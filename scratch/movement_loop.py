@@ -44,12 +44,20 @@ del items
 out = tempfile.mkdtemp()
 run.run_movement(net, subj, logdir=out, device=dev, test_num=2)                      # warm-up (writer threads, tables)
 torch.cuda.synchronize(); t0 = time.perf_counter()
+cfg.amd.loop_timing = True
 res = run.run_movement(net, subj, render_folder_name='timed', logdir=out, device=dev)
 torch.cuda.synchronize(); loop = (time.perf_counter() - t0) / n
-print('%s: %d frames, %.0f rays per frame; pure render %.2f ms per frame; run_movement %.2f ms per frame (%.2f fps); '
-      'loop / pure = %.3f' % ('lens (1024^2 PNGs, distortion, scale 0.5)' if lens else 'plain (512^2 PNGs)', n, rays,
-                              pure * 1e3, loop * 1e3, 1 / loop, loop / pure), flush=True)
-print('psnr', res['metrics'])
 from humannerf_amd import render
+first = render.render_frames.last_prefetch['wait_ms'][0] * 1e-3            # pipeline fill: the first frame has to be built
+steady = (loop * n - first) / n
+print('%s: %d frames, %.0f rays per frame; pure render %.2f ms per frame; run_movement %.2f ms per frame (%.2f fps), '
+      'loop / pure = %.3f; without the %.0f ms the first frame takes to build: %.2f ms per frame, loop / pure = %.3f'
+      % ('lens (1024^2 PNGs, distortion, scale 0.5)' if lens else 'plain (512^2 PNGs)', n, rays,
+         pure * 1e3, loop * 1e3, 1 / loop, loop / pure, first * 1e3, steady * 1e3, steady / pure), flush=True)
+print('psnr', res['metrics'])
 lp = render.render_frames.last_prefetch
 print('prefetch: build ms median %.1f max %.1f; renderer waited ms median %.2f max %.1f' % (np.median(lp['build_ms']), max(lp['build_ms']), np.median(lp['wait_ms']), max(lp['wait_ms'])))
+print('main thread per frame (median ms): submit %.2f, wait for image %.2f, on_image %.2f' % tuple(np.median(lp[k]) for k in ('submit_ms', 'image_wait_ms', 'on_image_ms')))
+
+if 'gpu_ms' in lp:
+    print('GPU per frame (events on the render stream): busy median %.2f ms, gap to the next frame median %.2f max %.2f ms' % (np.median(lp['gpu_ms']), np.median(lp['gpu_gap_ms']), max(lp['gpu_gap_ms'])))
