@@ -204,7 +204,9 @@ def main():
                                'perturb=0, ' + ('rgb/alpha/depth outputs' if args.lean else 'all 11 outputs of the reference Network.forward')
                                + '; seeded random weights of the default architecture',
                    'rays_per_step_per_gpu': R, 'samples_per_ray': S, 'ray_chunk': int(cfg.chunk),
-                   'mlp_mode': args.mode, 'parallelism': 'frames sharded over %d GPU(s), no collective' % world},
+                   'mlp_mode': args.mode, 'parallelism': 'frames sharded over %d GPU(s), no collective' % world,
+                   'f16_range_guard': "%s (cfg.amd.f16_range_guard: the default; 'full' guards every chunk of every frame at -3 %% rays/s)"
+                                      % cfg.amd.get('f16_range_guard', 'audit')},
         'dist_backend': 'none' if dist is None else dist.get_backend(),       # 'nccl' IS RCCL on ROCm
         'dist_world_size': 1 if dist is None else dist.get_world_size(),
         'roofline': roofline,

@@ -137,6 +137,9 @@ _DEFAULTS = {
         # the flag is up: 'raise' ActivationRangeError | 'f32' = warn and render every later frame with the exact fp32
         # MFMA kernels (the flagged frames are wrong: render loops re-render them) | 'ignore'
         'on_f16_range': 'raise',
+        # which launches carry the guard (it costs 3 % of a frame): 'audit' = every ray chunk of the first frame after a
+        # weight change, then one rotating chunk per frame | 'full' = every chunk of every frame | 'off'
+        'f16_range_guard': 'audit',
         # materialise the per-sample diagnostic outputs the reference always
         # returns (backward_motion_weights, xyz_on_rays, ...; ~17 KB/ray).
         'diagnostics': True,

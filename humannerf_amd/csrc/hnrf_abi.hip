@@ -162,8 +162,11 @@ extern "C" int hnrf_render_frame_fwd(const float* rays_o, const float* rays_d, c
         const int* cc = cull ? c.count : nullptr;
         float* xyz = diag ? xyz_on_rays + r0 * S * 3 : c.xyz;
         const float* cnl_in = c.x_skel;
+        // f16-range guard (hnrf.h): every chunk, none, or the one chunk the caller's rotating index names
+        int cmode = mode & (HNRF_MLP_ARITH_MASK | HNRF_MLP_NO_RANGE_GUARD);
+        if ((mode & HNRF_MLP_GUARD_ONE_CHUNK) && (int64_t)((unsigned)mode >> 16) % nchunk != i) cmode |= HNRF_MLP_NO_RANGE_GUARD;
         if (nr_packed) {
-            if ((rc = hnrf_nonrigid_fwd_sparse(c.x_skel, hann_w, nr_packed, mode, (int64_t)P, ci, cc, xyz,
+            if ((rc = hnrf_nonrigid_fwd_sparse(c.x_skel, hann_w, nr_packed, cmode, (int64_t)P, ci, cc, xyz,
                                                diag ? offsets + r0 * S * 3 : nullptr, st))) return rc;
             cnl_in = xyz;
         } else if (diag) {                                        // network.py:276-277: xyz = x_skel, offsets = 0
@@ -171,7 +174,7 @@ extern "C" int hnrf_render_frame_fwd(const float* rays_o, const float* rays_d, c
             HNRF_HIP(hipMemsetAsync(offsets + r0 * S * 3, 0, P * 12, st));
         }
         if (mlp_events) (void)hipEventRecord((hipEvent_t)mlp_events[2 * i], st);
-        rc = hnrf_canonical_fwd_sparse(cnl_in, cnl_packed, mode, (int64_t)P, ci, cc, c.raw, st);
+        rc = hnrf_canonical_fwd_sparse(cnl_in, cnl_packed, cmode, (int64_t)P, ci, cc, c.raw, st);
         if (mlp_events) (void)hipEventRecord((hipEvent_t)mlp_events[2 * i + 1], st);
         if (rc) return rc;
         if ((rc = hnrf_composite_fwd(c.raw, c.mask, c.z, rays_d + 3 * r0, diag ? cnl_in : nullptr, bgcolor, R, S,

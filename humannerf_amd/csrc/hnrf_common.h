@@ -51,11 +51,11 @@ size_t nonrigid16_status_offset();
 int canonical16_pack(const float* const* w, const float* const* b, void* packed, hipStream_t st);
 int nonrigid16_pack(const float* const* w, const float* const* b, const float* cond, void* packed, hipStream_t st);
 int canonical16_fwd(const float* xyz, const void* packed, int64_t P, float* raw, const int* idx, const int* count,
-                    hipStream_t st);
+                    bool guard, hipStream_t st);
 int canonical16_fwd_train(const float* xyz, const void* packed, int64_t P, float* raw, float* pe_out, float* acts,
                           uint32_t* relu_bits, int half, hipStream_t st);
 int nonrigid16_fwd(const float* x_skel, const float* hann_w, const void* packed, int64_t P, float* xyz,
-                   float* offsets, const int* idx, const int* count, hipStream_t st);
+                   float* offsets, const int* idx, const int* count, bool guard, hipStream_t st);
 
 int nonrigid16_fwd_train(const float* x_skel, const float* hann_w, const void* packed, int64_t P, float* xyz,
                          float* offsets, float* pe_out, float* acts, uint32_t* relu_bits, int half, hipStream_t st);

@@ -456,6 +456,8 @@ extern "C" int hnrf_canonical_fwd(const float* xyz, const void* packed, int mode
 }
 extern "C" int hnrf_canonical_fwd_sparse(const float* xyz, const void* packed, int mode, int64_t P, const int* idx,
                                          const int* count, float* raw, void* stream) {
+    const bool guard = !(mode & HNRF_MLP_NO_RANGE_GUARD);         // (HNRF_MLP_GUARD_ONE_CHUNK concerns hnrf_render_frame_fwd only)
+    mode &= HNRF_MLP_ARITH_MASK;
     HNRF_REQUIRE(xyz && packed && raw, HNRF_E_ARG, "hnrf_canonical_fwd: null pointer");
     HNRF_REQUIRE((idx == nullptr) == (count == nullptr), HNRF_E_ARG, "hnrf_canonical_fwd: idx and count go together");
     HNRF_REQUIRE(mode == HNRF_MLP_F32 || mode == HNRF_MLP_F16X3, HNRF_E_UNSUPPORTED,
@@ -464,7 +466,7 @@ extern "C" int hnrf_canonical_fwd_sparse(const float* xyz, const void* packed, i
     HNRF_REQUIRE((((uintptr_t)packed | (uintptr_t)raw) & 15) == 0, HNRF_E_ARG,
                  "hnrf_canonical_fwd: packed/raw must be 16-byte aligned");
     if (P == 0) return HNRF_OK;
-    if (mode == HNRF_MLP_F16X3) return canonical16_fwd(xyz, packed, P, raw, idx, count, (hipStream_t)stream);
+    if (mode == HNRF_MLP_F16X3) return canonical16_fwd(xyz, packed, P, raw, idx, count, guard, (hipStream_t)stream);
     hipLaunchKernelGGL(canonical_f32_kernel<false>, dim3((unsigned)((P + 127) / 128)), dim3(256), 0,
                        (hipStream_t)stream, xyz, (const float*)packed, P, (float4*)raw, nullptr, nullptr, nullptr, idx, count);
     return check_launch("hnrf_canonical_fwd");
@@ -497,6 +499,8 @@ extern "C" int hnrf_nonrigid_fwd(const float* x_skel, const float* hann_w, const
 extern "C" int hnrf_nonrigid_fwd_sparse(const float* x_skel, const float* hann_w, const void* packed, int mode,
                                         int64_t P, const int* idx, const int* count, float* xyz, float* offsets,
                                         void* stream) {
+    const bool guard = !(mode & HNRF_MLP_NO_RANGE_GUARD);
+    mode &= HNRF_MLP_ARITH_MASK;
     HNRF_REQUIRE(x_skel && hann_w && packed && xyz, HNRF_E_ARG, "hnrf_nonrigid_fwd: null pointer");
     HNRF_REQUIRE((idx == nullptr) == (count == nullptr), HNRF_E_ARG, "hnrf_nonrigid_fwd: idx and count go together");
     HNRF_REQUIRE(mode == HNRF_MLP_F32 || mode == HNRF_MLP_F16X3, HNRF_E_UNSUPPORTED,
@@ -505,7 +509,7 @@ extern "C" int hnrf_nonrigid_fwd_sparse(const float* x_skel, const float* hann_w
     HNRF_REQUIRE(((uintptr_t)packed & 15) == 0, HNRF_E_ARG, "hnrf_nonrigid_fwd: packed must be 16-byte aligned");
     if (P == 0) return HNRF_OK;
     if (mode == HNRF_MLP_F16X3)
-        return nonrigid16_fwd(x_skel, hann_w, packed, P, xyz, offsets, idx, count, (hipStream_t)stream);
+        return nonrigid16_fwd(x_skel, hann_w, packed, P, xyz, offsets, idx, count, guard, (hipStream_t)stream);
     hipLaunchKernelGGL(nonrigid_f32_kernel<false>, dim3((unsigned)((P + 127) / 128)), dim3(256), 0,
                        (hipStream_t)stream, x_skel, hann_w, (const float*)packed, P, xyz, offsets, nullptr, nullptr, nullptr, idx, count);
     return check_launch("hnrf_nonrigid_fwd");

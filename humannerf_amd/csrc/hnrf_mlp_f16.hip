@@ -267,6 +267,7 @@ struct Pipe {
     unsigned bias_off;   // byte offset of the current tile's bias record
     int wave;
     unsigned long long sat;   // lanes whose activations came near the f16 clamp (sat_check_frag)
+    bool guard;               // compile-time constant of the kernel instance (template parameter GUARD)
 #ifdef HNRF_STAMP
     unsigned long long t_last, sum_k, sum_b;   // diagnostic build only: cycles in k-loops / between them
 #endif
@@ -301,12 +302,21 @@ __device__ __forceinline__ void epi_pair(const f32x16& a1, const f32x16& a2, int
 // ABSOLUTE floor of 3e-8 on activations of order 0.1 .. 1 -- what a dot product over them sees is the same.  The
 // products wh . xl then carry no 2^11 and go into the FIRST accumulator; wl keeps its lift (weights are packed
 // offline and 2^-12 |w| would sit far down in the subnormals).
-// f16-range guard of the inference kernels.  The clamp above 65504 is silent: a checkpoint whose hidden activations
-// leave the f16 range would render a wrong image without any error.  When a B-operand fragment is complete (every
-// fourth pair) its 8 non-negative halves are folded with three v_pk_max_u16 and compared -- as integers, which order
-// like the values and put +inf / NaN on top -- against SAT_HALF; the verdict lands in an SGPR pair (no VGPR lives on:
-// these kernels sit at the 256 + 256 register limit, one more live VGPR sent the two-group kernel to scratch), and the
-// kernel ORs HNRF_STATUS_F16_RANGE into the image's status word at its end.  5 VALU per 8 values, in the MFMA shadow.
+// f16-range guard of the inference kernels.  The split v = hi + lo holds below the f16 range; the epilogue clamps
+// post-ReLU activations at 65504, and a checkpoint whose hidden activations get there would render a wrong image without
+// any error.  GUARDED kernel instances (template parameter GUARD, Pipe::guard) therefore look at every finished
+// B-operand fragment (every fourth pair): its 8 non-negative halves are folded with three v_pk_max_u16 and compared --
+// as integers, which order like the values and put +inf / NaN on top -- against SAT_HALF; the verdict lands in an SGPR
+// pair (no VGPR lives on: these kernels sit at the 256 + 256 register limit, one more live VGPR sent the two-group
+// kernel to scratch), and the kernel raises HNRF_STATUS_F16_RANGE in the image's status word at its end.
+// Cost, A/B on one box: 5 VALU per 8 values = +2.5 % canonical-kernel time, -3.0 % rays/s on the headline frame -- which
+// is why the callers can ask for unguarded instances (HNRF_MLP_NO_RANGE_GUARD / HNRF_MLP_GUARD_ONE_CHUNK, hnrf.h).
+// Two things that did not work: (1) the hardware's own sticky overflow bit -- without the clamp an overflowing
+// v_cvt_pk_f16_f32 gives +inf, and TRAPSTS.EXCP[3] read with s_getreg_b32 at the kernel's end would cost nothing: on
+// gfx950 the bit stays 0 with traps disabled (measured; the poisoned values then die in the next layer's ReLU, whose
+// v_max_f32 drops NaN); (2) a v_max3_f32 running maximum: 4 VALU per 8 values but one more live VGPR (see above).
+// The inline asm needs its "scc" clobber: s_or_b64 writes SCC, and without it hipcc scheduled the block between an
+// s_add_u32 / s_addc_u32 pair -- a hit then added a carry, i.e. 4 GiB, to a weight pointer (memory fault).
 constexpr unsigned SAT_HALF = 0x7B53u;      // f16(60000)
 __device__ __forceinline__ void sat_check_frag(const h16x8& hi, unsigned long long& sflag) {
     typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
@@ -316,8 +326,7 @@ __device__ __forceinline__ void sat_check_frag(const h16x8& hi, unsigned long lo
     const u16x2 m = __builtin_elementwise_max(__builtin_elementwise_max(a, b), __builtin_elementwise_max(c, d));
     const unsigned u = __builtin_bit_cast(unsigned, m);
     asm volatile("v_cmp_le_u32 vcc, %2, %1\n\ts_or_b64 %0, %0, vcc\n\tv_cmp_le_u16 vcc, %3, %1\n\ts_or_b64 %0, %0, vcc"
-                 : "+s"(sflag) : "v"(u), "s"(SAT_HALF << 16), "s"(SAT_HALF) : "vcc", "scc");   // (s_or_b64 writes SCC: without
-    // the clobber hipcc schedules this between an s_add_u32 / s_addc_u32 pair and a hit adds a carry -- 4 GiB -- to a pointer)
+                 : "+s"(sflag) : "v"(u), "s"(SAT_HALF << 16), "s"(SAT_HALF) : "vcc", "scc");
 }
 __device__ __forceinline__ void raise_f16_range(const char* packed, int64_t off, unsigned long long sflag) {
     // a plain store, not an atomic OR: the word has this one bit, every writer writes the same value
@@ -328,7 +337,7 @@ __device__ __forceinline__ void raise_f16_range(const char* packed, int64_t off,
 
 template <bool RELU>
 __device__ __forceinline__ void epi_pair_u(const f32x16& a1, const f32x16& a2, int i, h16x8& hi, h16x8& lo,
-                                           unsigned long long& sflag) {
+                                           unsigned long long& sflag, bool guard) {
     float x0 = fmaf(a2[2 * i], LO_INV, a1[2 * i]);
     float x1 = fmaf(a2[2 * i + 1], LO_INV, a1[2 * i + 1]);
     if (RELU) {
@@ -348,7 +357,7 @@ __device__ __forceinline__ void epi_pair_u(const f32x16& a1, const f32x16& a2, i
     hi[e + 1] = hh[1];
     lo[e] = ll[0];
     lo[e + 1] = ll[1];
-    if (RELU && (i & 3) == 3) sat_check_frag(hi, sflag);
+    if (RELU && guard && (i & 3) == 3) sat_check_frag(hi, sflag);
 }
 __device__ __forceinline__ void split8_u(const float (&v)[8], h16x8& hi, h16x8& lo) {
 #pragma unroll
@@ -650,7 +659,7 @@ __device__ __forceinline__ void layer16(Pipe& p, int nb1, int nb2, h16x8 (&bh)[N
 #pragma unroll
                     for (int i = 0; i < 8; ++i)
                         if ((i * (NK - 1)) / 8 == ks) {
-                            epi_pair_u<true>(*pend1, *pend2, i, bh[NKB - 2 + (i >> 2)], bl[NKB - 2 + (i >> 2)], p.sat);
+                            epi_pair_u<true>(*pend1, *pend2, i, bh[NKB - 2 + (i >> 2)], bl[NKB - 2 + (i >> 2)], p.sat, p.guard);
                             asm volatile("" : "+v"(bh[NKB - 2 + (i >> 2)]), "+v"(bl[NKB - 2 + (i >> 2)]));
                         }
                 }
@@ -682,7 +691,7 @@ __device__ __forceinline__ void layer16(Pipe& p, int nb1, int nb2, h16x8 (&bh)[N
                                 sc->fout[16 * (t - 1) + 2 * i] = fmaf(pacc2[2 * i], LO_INV, pacc1[2 * i]);
                                 sc->fout[16 * (t - 1) + 2 * i + 1] = fmaf(pacc2[2 * i + 1], LO_INV, pacc1[2 * i + 1]);
                             } else
-                            epi_pair_u<RELU>(pacc1, pacc2, i, oh[2 * (t - 1) + (i >> 2)], ol[2 * (t - 1) + (i >> 2)], p.sat);
+                            epi_pair_u<RELU>(pacc1, pacc2, i, oh[2 * (t - 1) + (i >> 2)], ol[2 * (t - 1) + (i >> 2)], p.sat, p.guard);
                             // pin the result here: without a use in this block hipcc sinks the whole
                             // epilogue to the first consumer (the next layer), out of the MFMA shadow
                             if constexpr (SAVE != SV_PE)
@@ -747,7 +756,7 @@ __device__ __forceinline__ void layer16(Pipe& p, int nb1, int nb2, h16x8 (&bh)[N
                 sc->fout[16 * (NT - 1) + 2 * i] = fmaf(pacc2[2 * i], LO_INV, pacc1[2 * i]);
                 sc->fout[16 * (NT - 1) + 2 * i + 1] = fmaf(pacc2[2 * i + 1], LO_INV, pacc1[2 * i + 1]);
             } else
-            epi_pair_u<RELU>(pacc1, pacc2, i, oh[2 * (NT - 1) + (i >> 2)], ol[2 * (NT - 1) + (i >> 2)], p.sat);
+            epi_pair_u<RELU>(pacc1, pacc2, i, oh[2 * (NT - 1) + (i >> 2)], ol[2 * (NT - 1) + (i >> 2)], p.sat, p.guard);
         }
         if constexpr (sv_fwd(SAVE)) {
 #pragma unroll
@@ -859,7 +868,7 @@ __device__ __forceinline__ void layer16x2(Pipe& p, unsigned stash_per_wave, int 
                     for (int j = 0; j < 16; ++j)
                         if ((j * NK) / 16 == ks) {
                             const int g = j >> 3, i = j & 7;
-                            epi_pair_u<RELU>(pacc1[g], pacc2[g], i, oh[g][2 * (t - 1) + (i >> 2)], ol[g][2 * (t - 1) + (i >> 2)], p.sat);
+                            epi_pair_u<RELU>(pacc1[g], pacc2[g], i, oh[g][2 * (t - 1) + (i >> 2)], ol[g][2 * (t - 1) + (i >> 2)], p.sat, p.guard);
                             asm volatile("" : "+v"(oh[g][2 * (t - 1) + (i >> 2)]), "+v"(ol[g][2 * (t - 1) + (i >> 2)]));
                         }
                 }
@@ -895,7 +904,7 @@ __device__ __forceinline__ void layer16x2(Pipe& p, unsigned stash_per_wave, int 
         } else {
 #pragma unroll
             for (int i = 0; i < 8; ++i)
-                epi_pair_u<RELU>(pacc1[g], pacc2[g], i, oh[g][2 * (NT - 1) + (i >> 2)], ol[g][2 * (NT - 1) + (i >> 2)], p.sat);
+                epi_pair_u<RELU>(pacc1[g], pacc2[g], i, oh[g][2 * (NT - 1) + (i >> 2)], ol[g][2 * (NT - 1) + (i >> 2)], p.sat, p.guard);
         }
     }
 }
@@ -912,6 +921,7 @@ __device__ __forceinline__ Pipe pipe_start(const char* packed, int64_t bias_img_
     p.ph = 0;
     p.bias_off = 0;
     p.sat = 0ull;
+    p.guard = false;
 #ifdef HNRF_STAMP
     p.t_last = __builtin_readcyclecounter();
     p.sum_k = p.sum_b = 0;
@@ -937,7 +947,7 @@ __device__ __forceinline__ void stash_pe(const Pipe& p, int ks, const float (&v)
 // SAVE (training forward): also writes pe_out [P,63], acts [8][P][256] (fp32 post-ReLU values, as combined in the
 // epilogue) and relu_bits [8][P][8] like canonical_f32_kernel<true>; no sparse form.  SAVE == SV_ACT_H: acts and
 // pe_out are f16 matrices ([8][P][256], [P][64] with column 63 zero) for hnrf_mlp_dw_h.
-template <int SAVE>
+template <int SAVE, bool GUARD = false>
 __global__ __launch_bounds__(256) void canonical_f16x3_kernel(const float* __restrict__ xyz,
                                                               const char* __restrict__ packed, int64_t P,
                                                               float4* __restrict__ raw, const int* __restrict__ idx,
@@ -952,6 +962,7 @@ __global__ __launch_bounds__(256) void canonical_f16x3_kernel(const float* __res
         if ((int64_t)blockIdx.x * 128 >= P) return;           // whole workgroup, before any DMA / barrier
     }
     Pipe p = pipe_start(packed, CNL16_BIAS, CNL16_BIAS_LDS, CNL16_SLAB, 4 * CNL16_NB_L0, 4 * CNL16_NB_L0, smem);
+    p.guard = GUARD && SAVE == SV_NONE;
     const int lane = threadIdx.x & 63, h = lane >> 5;
     const int64_t slot = ((int64_t)blockIdx.x * 4 + p.wave) * 32 + (lane & 31);
     const int64_t sclamp = slot < P ? slot : P - 1;
@@ -1021,7 +1032,7 @@ __global__ __launch_bounds__(256) void canonical_f16x3_kernel(const float* __res
     const float hs = ob[8];
     if (h == 0 && slot < P)
         raw[sample] = make_float4(fmaf(last[0], hs, ob[0]), fmaf(last[1], hs, ob[1]), fmaf(last[2], hs, ob[2]), fmaf(last[3], hs, ob[3]));
-    if constexpr (SAVE == SV_NONE) raise_f16_range(packed, CNL16_STATUS, p.sat);
+    if constexpr (SAVE == SV_NONE && GUARD) raise_f16_range(packed, CNL16_STATUS, p.sat);
 #ifdef HNRF_STAMP
     if (threadIdx.x == 0 && blockIdx.x < 4096) {   // stamps leave through a buffer nothing else reads
         const unsigned long long te = __builtin_readcyclecounter();
@@ -1128,6 +1139,7 @@ __global__ __launch_bounds__(256) void nonrigid_f16x3_kernel(const float* __rest
 constexpr int NR16X2_SLAB = 24 * 1024;
 constexpr int NR16X2_STASH = 64 * 1024;
 
+template <bool GUARD>
 __global__ __launch_bounds__(256) void nonrigid_f16x3_x2_kernel(const float* __restrict__ x_skel,
                                                                 const float* __restrict__ hann_w,
                                                                 const char* __restrict__ packed, int64_t P,
@@ -1142,6 +1154,7 @@ __global__ __launch_bounds__(256) void nonrigid_f16x3_x2_kernel(const float* __r
     // pipe_start lays the LDS out as [bias | PE_STASH | ring]: the stash of this kernel is twice as large
     Pipe p = pipe_start(packed, NR16_BIAS, NR16_BIAS_LDS, NR16X2_SLAB, 2 * NR16_NB_L0, 2 * NR16_NB_L0, smem,
                         NR16X2_STASH);
+    p.guard = GUARD;
     constexpr unsigned SPW = NR16X2_STASH / 4;                  // stash bytes per wave
     const int lane = threadIdx.x & 63, h = lane >> 5;
     int64_t sidx[2];
@@ -1207,7 +1220,7 @@ __global__ __launch_bounds__(256) void nonrigid_f16x3_x2_kernel(const float* __r
             }
         }
     }
-    raise_f16_range(packed, NR16_STATUS, p.sat);
+    if constexpr (GUARD) raise_f16_range(packed, NR16_STATUS, p.sat);
 }
 
 // ============================================================================ dX chain, split-f16
@@ -1617,12 +1630,19 @@ int nonrigid16_pack(const float* const* w, const float* const* b, const float* c
 }
 
 int canonical16_fwd(const float* xyz, const void* packed, int64_t P, float* raw, const int* idx, const int* count,
-                    hipStream_t st) {
+                    bool guard, hipStream_t st) {
     constexpr int lds = CNL16_BIAS_LDS + PE_STASH + RING * CNL16_SLAB;
-    static unsigned long long lds_done = 0;
-    if (int rc = reserve_lds((const void*)canonical_f16x3_kernel<SV_NONE>, lds, lds_done, "hnrf_canonical_fwd (f16x3)")) return rc;
-    hipLaunchKernelGGL(canonical_f16x3_kernel<SV_NONE>, dim3((unsigned)((P + 127) / 128)), dim3(256), lds, st, xyz,
-                       (const char*)packed, P, (float4*)raw, idx, count, nullptr, nullptr, nullptr);
+    static unsigned long long lds_done = 0, lds_done_g = 0;
+    const dim3 grid((unsigned)((P + 127) / 128));
+    if (guard) {
+        if (int rc = reserve_lds((const void*)canonical_f16x3_kernel<SV_NONE, true>, lds, lds_done_g, "hnrf_canonical_fwd (f16x3)")) return rc;
+        hipLaunchKernelGGL((canonical_f16x3_kernel<SV_NONE, true>), grid, dim3(256), lds, st, xyz, (const char*)packed, P,
+                           (float4*)raw, idx, count, nullptr, nullptr, nullptr);
+    } else {
+        if (int rc = reserve_lds((const void*)canonical_f16x3_kernel<SV_NONE, false>, lds, lds_done, "hnrf_canonical_fwd (f16x3)")) return rc;
+        hipLaunchKernelGGL((canonical_f16x3_kernel<SV_NONE, false>), grid, dim3(256), lds, st, xyz, (const char*)packed, P,
+                           (float4*)raw, idx, count, nullptr, nullptr, nullptr);
+    }
     return check_launch("hnrf_canonical_fwd (f16x3)");
 }
 
@@ -1644,16 +1664,19 @@ int canonical16_fwd_train(const float* xyz, const void* packed, int64_t P, float
 }
 
 int nonrigid16_fwd(const float* x_skel, const float* hann_w, const void* packed, int64_t P, float* xyz,
-                   float* offsets, const int* idx, const int* count, hipStream_t st) {
-    constexpr int lds = NR16_BIAS_LDS + PE_STASH + RING * NR16_SLAB;
-    static unsigned long long lds_done = 0;
-    if (int rc = reserve_lds((const void*)nonrigid_f16x3_kernel<SV_NONE>, lds, lds_done, "hnrf_nonrigid_fwd (f16x3)")) return rc;
-    (void)lds;
+                   float* offsets, const int* idx, const int* count, bool guard, hipStream_t st) {
     constexpr int lds2 = NR16_BIAS_LDS + NR16X2_STASH + RING * NR16X2_SLAB;
-    static unsigned long long lds2_done = 0;
-    if (int rc = reserve_lds((const void*)nonrigid_f16x3_x2_kernel, lds2, lds2_done, "hnrf_nonrigid_fwd (f16x3)")) return rc;
-    hipLaunchKernelGGL(nonrigid_f16x3_x2_kernel, dim3((unsigned)((P + 255) / 256)), dim3(256), lds2, st, x_skel, hann_w,
-                       (const char*)packed, P, xyz, offsets, idx, count);
+    static unsigned long long lds2_done = 0, lds2_done_g = 0;
+    const dim3 grid((unsigned)((P + 255) / 256));
+    if (guard) {
+        if (int rc = reserve_lds((const void*)nonrigid_f16x3_x2_kernel<true>, lds2, lds2_done_g, "hnrf_nonrigid_fwd (f16x3)")) return rc;
+        hipLaunchKernelGGL(nonrigid_f16x3_x2_kernel<true>, grid, dim3(256), lds2, st, x_skel, hann_w, (const char*)packed, P, xyz,
+                           offsets, idx, count);
+    } else {
+        if (int rc = reserve_lds((const void*)nonrigid_f16x3_x2_kernel<false>, lds2, lds2_done, "hnrf_nonrigid_fwd (f16x3)")) return rc;
+        hipLaunchKernelGGL(nonrigid_f16x3_x2_kernel<false>, grid, dim3(256), lds2, st, x_skel, hann_w, (const char*)packed, P, xyz,
+                           offsets, idx, count);
+    }
     return check_launch("hnrf_nonrigid_fwd (f16x3)");
 }
 

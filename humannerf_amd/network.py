@@ -438,6 +438,7 @@ class Network(nn.Module):
         # f16-range guard of inference (the training side has autograd.OperandRangeGuard): pinned copy of the two
         # images' status words, the event behind it, and the mode forced after a hit with cfg.amd.on_f16_range = 'f32'
         self._range_watch = None
+        self._guard_state = None    # [canonical pack key, frames rendered with it]: the audit schedule of _guard_plan
         self._forced_mode = None
         self.f16_range_hits = self.f16_range_watched = self.f16_range_checked = 0
         self._vol_cache = None    # (key, priors, volume)
@@ -459,6 +460,29 @@ class Network(nn.Module):
         return self._forced_mode or amd_option('mlp_mode', 'f16x3')
 
     # f16-range guard ---------------------------------------------------------
+    def _guard_plan(self, mode, n_chunks):
+        """Which ray chunks of this frame run the GUARDED kernel instances (cfg.amd.f16_range_guard; the guard costs
+        3 % of the frame).  'full': all.  'off': none.  'audit' (default): all chunks of the first frame after the
+        weights changed -- a checkpoint that does not fit the f16 range shows on its first frame -- then one chunk per
+        frame, rotating, so that every region of the image and every pose is sampled as a sequence goes on.
+        Returns (mode string for hnrf_render_frame_fwd, set of guarded chunk numbers or None = all)."""
+        if mode != 'f16x3':
+            return mode, None
+        policy = amd_option('f16_range_guard', 'audit')
+        if policy == 'full':
+            return mode, None
+        if policy == 'off':
+            return mode + '+noguard', set()
+        key = self._cnl_pack[0] if self._cnl_pack is not None else None
+        if self._guard_state is None or self._guard_state[0] != key:
+            self._guard_state = [key, 0]
+        frame_no = self._guard_state[1]
+        self._guard_state[1] += 1
+        if frame_no == 0:
+            return mode, None
+        k = (frame_no - 1) % max(1, n_chunks)
+        return mode + '+guard1:%d' % k, {k}
+
     def _watch_f16_range(self, cnl_packed, nr_packed, mode):
         """Called after a frame's inference kernels are queued: copies the two images' status words into a pinned slot
         -- behind the kernels in stream order, in front of the next frame's pack, which zeroes the non-rigid image's
@@ -625,16 +649,20 @@ class Network(nn.Module):
             # the whole frame in one library call: chunk loop of network.py:330-352, results straight into whole-frame
             # tensors (the reference concatenates per-chunk results: one more pass over 17 KB per ray); optionally K1 of
             # the next chunk on a side stream under the MLP kernels of the current one (cfg.amd.overlap_warp)
+            gmode, guarded = self._guard_plan(mode, -(-N // int(cfg.chunk)))
             out, self._workspace = ops.render_frame(
                 rays_o, rays_d, near, far, t_rand, motion_Rs, motion_Ts, vol, bbox_min, bbox_scale, hann_w, nr_packed,
-                cnl_packed, bg, S, int(cfg.chunk), mode, diagnostics=diag,
+                cnl_packed, bg, S, int(cfg.chunk), gmode, diagnostics=diag,
                 cull_eps=0.0 if diag else float(amd_option('cull_eps', 0.0)), workspace=self._workspace,
                 overlap=bool(amd_option('overlap_warp', False)), mlp_event_log=self.mlp_event_log)
-            if mode == 'f16x3':
+            if mode == 'f16x3' and guarded != set():
                 self._watch_f16_range(cnl_packed, nr_packed, mode)
         else:
             chunks = []
-            for i in range(0, N, int(cfg.chunk)):                          # network.py:333
+            guarded = None
+            if not train_path:
+                _, guarded = self._guard_plan(mode, -(-N // int(cfg.chunk)))
+            for ci, i in enumerate(range(0, N, int(cfg.chunk))):           # network.py:333
                 sl = slice(i, min(i + int(cfg.chunk), N))
                 if train_path:
                     chunks.append(self._render_rays_train(rays_o[sl], rays_d[sl], near[sl], far[sl],
@@ -645,9 +673,10 @@ class Network(nn.Module):
                 chunks.append(self._render_rays(rays_o[sl], rays_d[sl], near[sl], far[sl],
                                                 None if t_rand is None else t_rand[sl],
                                                 motion_Rs, motion_Ts, vol, bbox_min, bbox_scale, hann_w,
-                                                nr_packed, cnl_packed, bg, S, mode, diag, None))
+                                                nr_packed, cnl_packed, bg, S,
+                                                mode if guarded is None or ci in guarded else mode + '+noguard', diag, None))
             out = {k: (torch.cat([c[k] for c in chunks], 0) if len(chunks) > 1 else chunks[0][k]) for k in chunks[0]}
-            if not train_path and mode == 'f16x3':
+            if not train_path and mode == 'f16x3' and guarded != set():
                 self._watch_f16_range(cnl_packed, nr_packed, mode)
         lead = list(rays_shape[:-1])
         return {k: v.reshape(lead + list(v.shape[1:])) for k, v in out.items()}

@@ -15,6 +15,24 @@ MLP_MODES = {'f32': 0, 'f16x3': 1}
 TRAIN_MODES = {'f32': 0, 'f16x3': 1, 'f16x3h': 2}
 
 
+NO_RANGE_GUARD, GUARD_ONE_CHUNK = 0x100, 0x200          # hnrf.h: HNRF_MLP_NO_RANGE_GUARD / HNRF_MLP_GUARD_ONE_CHUNK
+
+
+def _mode_arg(mode):
+    """``mode`` argument of the forward entry points: 'f32' | 'f16x3', optionally with the f16-range guard selection
+    (hnrf.h) appended -- 'f16x3+noguard' (unguarded kernel instances) or 'f16x3+guard1:<k>' (hnrf_render_frame_fwd:
+    only ray chunk k % n_chunks is guarded).  Plain names guard every launch."""
+    base, _, opt = mode.partition('+')
+    m = MLP_MODES[base]
+    if not opt:
+        return m
+    if opt == 'noguard':
+        return m | NO_RANGE_GUARD
+    if opt.startswith('guard1:'):
+        return m | GUARD_ONE_CHUNK | ((int(opt[7:]) & 0x7fff) << 16)
+    raise ValueError('unknown mode option %r' % mode)
+
+
 def _ptr(t):
     return 0 if t is None else t.data_ptr()
 
@@ -95,7 +113,7 @@ def nonrigid(x_skel, hann_w, packed, mode='f32', want_offsets=False, xyz_out=Non
     xyz = xyz_out if xyz_out is not None else torch.empty_like(x_skel)
     offsets = (offsets_out if offsets_out is not None else torch.empty_like(x_skel)) if want_offsets else None
     assert xyz.shape == x_skel.shape and (offsets is None or offsets.shape == x_skel.shape)
-    _lib.check(lib.hnrf_nonrigid_fwd(_ptr(x_skel), _ptr(hann_w), _ptr(packed), MLP_MODES[mode], P, _ptr(xyz),
+    _lib.check(lib.hnrf_nonrigid_fwd(_ptr(x_skel), _ptr(hann_w), _ptr(packed), _mode_arg(mode), P, _ptr(xyz),
                                      _ptr(offsets), _stream()), 'hnrf_nonrigid_fwd')
     return xyz, offsets
 
@@ -124,7 +142,7 @@ def status_word(packed, which, mode):
     (hnrf_canonical_status_offset / hnrf_nonrigid_status_offset): the f16x3 inference kernels OR
     STATUS_F16_RANGE into it when an activation came within reach of the f16 clamp."""
     lib = _lib.load()
-    off = (lib.hnrf_canonical_status_offset if which == 'canonical' else lib.hnrf_nonrigid_status_offset)(MLP_MODES[mode])
+    off = (lib.hnrf_canonical_status_offset if which == 'canonical' else lib.hnrf_nonrigid_status_offset)(MLP_MODES[mode.partition('+')[0]])
     if off == 0:
         return None
     assert off % 4 == 0 and packed.dtype == torch.float32
@@ -140,7 +158,7 @@ def canonical(xyz, packed, mode='f32'):
     _chk(xyz, packed)
     P = xyz.numel() // 3
     raw = torch.empty(*xyz.shape[:-1], 4, device=xyz.device)
-    _lib.check(lib.hnrf_canonical_fwd(_ptr(xyz), _ptr(packed), MLP_MODES[mode], P, _ptr(raw), _stream()),
+    _lib.check(lib.hnrf_canonical_fwd(_ptr(xyz), _ptr(packed), _mode_arg(mode), P, _ptr(raw), _stream()),
                'hnrf_canonical_fwd')
     return raw
 
@@ -209,7 +227,7 @@ def render_rays(rays_o, rays_d, near, far, t_rand, motion_Rs, motion_Ts, vol, bb
     _lib.check(lib.hnrf_render_rays_fwd(_ptr(rays_o), _ptr(rays_d), _ptr(near), _ptr(far), _ptr(t_rand),
                                         _ptr(motion_Rs), _ptr(motion_Ts), _ptr(vol), _ptr(bbox_min),
                                         _ptr(bbox_scale), _ptr(hann_w), _ptr(nr_packed), _ptr(cnl_packed),
-                                        _ptr(bgcolor), MLP_MODES[mode], float(cull_eps), R, S, motion_Rs.shape[0], vol.shape[-1],
+                                        _ptr(bgcolor), _mode_arg(mode), float(cull_eps), R, S, motion_Rs.shape[0], vol.shape[-1],
                                         _ptr(workspace), workspace.numel() * workspace.element_size(),
                                         _ptr(out['rgb']), _ptr(out['alpha']), _ptr(out['depth']),
                                         ev[0], ev[1], _stream()),
@@ -268,7 +286,7 @@ def render_frame(rays_o, rays_d, near, far, t_rand, motion_Rs, motion_Ts, vol, b
         mlp_arr = (ctypes.c_void_p * (2 * nchunk))(*[e.cuda_event for p in pairs for e in p])
     _lib.check(lib.hnrf_render_frame_fwd(
         _ptr(rays_o), _ptr(rays_d), _ptr(near), _ptr(far), _ptr(t_rand), _ptr(motion_Rs), _ptr(motion_Ts), _ptr(vol),
-        _ptr(bbox_min), _ptr(bbox_scale), _ptr(hann_w), _ptr(nr_packed), _ptr(cnl_packed), _ptr(bgcolor), MLP_MODES[mode],
+        _ptr(bbox_min), _ptr(bbox_scale), _ptr(hann_w), _ptr(nr_packed), _ptr(cnl_packed), _ptr(bgcolor), _mode_arg(mode),
         float(cull_eps), N, S, B, G, chunk, _ptr(workspace), workspace.numel() * 4, g('rgb'), g('alpha'), g('depth'),
         g('weights_on_rays'), g('rgb_on_rays'), g('cnl_xyz'), g('cnl_rgb'), g('cnl_weight'), g('xyz_on_rays'),
         g('backward_motion_weights'), g('offsets'), side.cuda_stream if side is not None else None, ev_arr, mlp_arr,
@@ -304,7 +322,7 @@ def render_rays_term(rays_o, rays_d, near, far, t_rand, motion_Rs, motion_Ts, vo
     _lib.check(lib.hnrf_render_rays_term_fwd(_ptr(rays_o), _ptr(rays_d), _ptr(near), _ptr(far), _ptr(t_rand),
                                              _ptr(motion_Rs), _ptr(motion_Ts), _ptr(vol), _ptr(bbox_min),
                                              _ptr(bbox_scale), _ptr(hann_w), _ptr(nr_packed), _ptr(cnl_packed),
-                                             _ptr(bgcolor), MLP_MODES[mode], float(cull_eps), float(term_eps), R, S,
+                                             _ptr(bgcolor), _mode_arg(mode), float(cull_eps), float(term_eps), R, S,
                                              motion_Rs.shape[0], vol.shape[-1], _ptr(workspace),
                                              workspace.numel() * workspace.element_size(), _ptr(out['rgb']),
                                              _ptr(out['alpha']), _ptr(out['depth']),
@@ -595,7 +613,7 @@ def canonical_sparse(xyz, packed, idx, count, mode='f32', raw=None):
     P = xyz.numel() // 3
     if raw is None:
         raw = torch.zeros(*xyz.shape[:-1], 4, device=xyz.device)
-    _lib.check(lib.hnrf_canonical_fwd_sparse(_ptr(xyz), _ptr(packed), MLP_MODES[mode], P, _ptr(idx), _ptr(count),
+    _lib.check(lib.hnrf_canonical_fwd_sparse(_ptr(xyz), _ptr(packed), _mode_arg(mode), P, _ptr(idx), _ptr(count),
                                              _ptr(raw), _stream()), 'hnrf_canonical_fwd_sparse')
     return raw
 
@@ -605,7 +623,7 @@ def nonrigid_sparse(x_skel, hann_w, packed, idx, count, mode='f32'):
     _chk(x_skel, hann_w, packed)
     P = x_skel.numel() // 3
     xyz = x_skel.clone()
-    _lib.check(lib.hnrf_nonrigid_fwd_sparse(_ptr(x_skel), _ptr(hann_w), _ptr(packed), MLP_MODES[mode], P, _ptr(idx),
+    _lib.check(lib.hnrf_nonrigid_fwd_sparse(_ptr(x_skel), _ptr(hann_w), _ptr(packed), _mode_arg(mode), P, _ptr(idx),
                                             _ptr(count), _ptr(xyz), 0, _stream()), 'hnrf_nonrigid_fwd_sparse')
     return xyz
 

@@ -60,6 +60,18 @@ const char* hnrf_last_error(void);
 #define HNRF_STATUS_F16_RANGE 1u
 size_t hnrf_canonical_status_offset(int mode);
 size_t hnrf_nonrigid_status_offset(int mode);
+/* The guard costs 5 VALU instructions per 8 activations (+2.5 % canonical-kernel time, -3.0 % rays/s on the
+ * 512x512x128 frame, measured A/B).  Flags OR-ed into the `mode` argument of the forward entry points select unguarded
+ * kernel instances; the low byte stays the arithmetic:
+ *   (none)                       every launch is guarded (the default of every entry point);
+ *   HNRF_MLP_NO_RANGE_GUARD      no launch is guarded -- the status words stay as they are;
+ *   HNRF_MLP_GUARD_ONE_CHUNK     hnrf_render_frame_fwd only: of the frame's ray chunks only number
+ *                                ((unsigned)mode >> 16) % n_chunks is guarded -- the caller rotates that index from
+ *                                frame to frame (an audit: humannerf_amd.network guards every chunk of the first frame
+ *                                after a weight change and one rotating chunk afterwards, cfg.amd.f16_range_guard). */
+#define HNRF_MLP_ARITH_MASK       0xff
+#define HNRF_MLP_NO_RANGE_GUARD   0x100
+#define HNRF_MLP_GUARD_ONE_CHUNK  0x200
 
 /* ---- K1: z-sampling + inverse-LBS warp ------------------------------------
  * Replaces Network._get_samples_along_ray / _stratified_sampling

@@ -34,3 +34,4 @@ for s in (1.0, scale):
     print('  out %x' % out.data_ptr(), flush=True)
     torch.cuda.synchronize()
     print('  after', int(word.item()), 'finite', bool(torch.isfinite(out).all()), flush=True)
+print('DONE', flush=True)

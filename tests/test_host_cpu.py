@@ -286,3 +286,34 @@ def test_patch_sampler_equals_reference_sampler_draw_for_draw():
         assert np.array_equal(a[0], b[0]) and np.array_equal(a[2], b[2])
         for k in a[1]:
             assert np.array_equal(a[1][k], b[1][k]), k
+
+
+def test_f16_range_guard_schedule():
+    """cfg.amd.f16_range_guard (the guard costs 3 % of a frame): 'audit' guards every ray chunk of the first frame
+    rendered with a set of weights, then one chunk per frame, rotating; a weight change starts over; 'full' / 'off'
+    guard everything / nothing; the exact fp32 mode has nothing to guard.  The mode strings are what ops hands to
+    the C ABI (HNRF_MLP_NO_RANGE_GUARD / HNRF_MLP_GUARD_ONE_CHUNK, include/hnrf.h)."""
+    from humannerf_amd import ops
+    from humannerf_amd.config import cfg
+    from humannerf_amd.network import Network
+    net = Network()
+    old = cfg.amd.get('f16_range_guard', 'audit')
+    try:
+        cfg.amd.f16_range_guard = 'audit'
+        net._cnl_pack = (('f16x3', 1), None)
+        assert net._guard_plan('f16x3', 8) == ('f16x3', None)
+        got = [net._guard_plan('f16x3', 8) for _ in range(9)]
+        assert [g[0] for g in got] == ['f16x3+guard1:%d' % (k % 8) for k in range(9)]
+        assert [g[1] for g in got] == [{k % 8} for k in range(9)]
+        net._cnl_pack = (('f16x3', 2), None)                                  # an optimizer step / a new checkpoint
+        assert net._guard_plan('f16x3', 8) == ('f16x3', None)
+        assert net._guard_plan('f16x3', 1) == ('f16x3+guard1:0', {0})         # one-chunk frames stay fully guarded
+        assert net._guard_plan('f32', 8) == ('f32', None)
+        cfg.amd.f16_range_guard = 'off'
+        assert net._guard_plan('f16x3', 8) == ('f16x3+noguard', set())
+        cfg.amd.f16_range_guard = 'full'
+        assert net._guard_plan('f16x3', 8) == ('f16x3', None)
+    finally:
+        cfg.amd.f16_range_guard = old
+    assert ops._mode_arg('f16x3') == 1 and ops._mode_arg('f32') == 0
+    assert ops._mode_arg('f16x3+noguard') == 0x101 and ops._mode_arg('f16x3+guard1:5') == 0x50201
