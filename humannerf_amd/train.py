@@ -46,6 +46,23 @@ class GroupedAdam(torch.optim.Adam):
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
         super().__init__(params, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, fused=True)
 
+    def load_state_dict(self, state_dict):
+        """Also accepts what the REFERENCE's optimizer wrote (trainer.py:356-364: a plain torch.optim.Adam -- groups with
+        ``fused`` None / False and per-parameter ``step`` counters that are Python numbers or CPU tensors).  torch
+        restores groups and step placement as saved; the fused multi-tensor launch of ``step`` needs every counter as a
+        float32 scalar ON the parameter's device, and the groups marked fused."""
+        super().load_state_dict(state_dict)
+        for group in self.param_groups:
+            group['fused'], group['foreach'] = True, False
+            group.setdefault('capturable', False)
+            group.setdefault('differentiable', False)
+            for p in group['params']:
+                st = self.state.get(p)
+                if st and 'step' in st:
+                    st['step'] = torch.as_tensor(float(st['step']), dtype=torch.float32).to(p.device)
+                    for k in ('exp_avg', 'exp_avg_sq'):
+                        st[k] = st[k].to(device=p.device, dtype=p.dtype)
+
     @torch.no_grad()
     def step(self, closure=None):
         assert closure is None

@@ -39,7 +39,7 @@ def test_hip_path_vs_eager_pytorch_rocm(seeded_params):
             'cnl_bbox_min_xyz', 'cnl_bbox_scale_xyz', 'bgcolor']
     data = {k: torch.from_numpy(np.ascontiguousarray(fr[k])).to(dev) for k in keys}
     cfg.perturb, cfg.N_samples = 0., 128
-    res = {}
+    res, errs = {}, {}
     try:
         for mode in ('f16x3', 'f32'):
             cfg.amd.mlp_mode = mode
@@ -53,12 +53,16 @@ def test_hip_path_vs_eager_pytorch_rocm(seeded_params):
                 torch.cuda.synchronize()
             res[mode] = (time.perf_counter() - t0) / 3
             err = float((out['rgb'] - ref['rgb']).abs().max())
-            assert err <= 1e-4, (mode, err)          # two fp32 GPU paths against each other
+            errs[mode] = err
+            # two fp32 evaluations against each other on all 262 144 rays: each is held to 2e-5 against the reference
+            # (tests/test_gpu_parity.py), so 4e-5 between them; measured 2.6e-5 (f16x3) on the driver's bench frame
+            assert err <= 4e-5, (mode, err)
     finally:
         cfg.amd.mlp_mode, cfg.amd.diagnostics, cfg.perturb = 'f16x3', True, 1.0
     print('\neager PyTorch-ROCm restatement: %.1f ms/frame = %.0f rays/s' % (t_eager * 1e3, R / t_eager))
     for mode, t in res.items():
-        print('HIP path %-6s: %.1f ms/frame = %.0f rays/s  (%.1fx eager)' % (mode, t * 1e3, R / t, t_eager / t))
+        print('HIP path %-6s: %.1f ms/frame = %.0f rays/s  (%.1fx eager), max |d rgb| vs eager %.2e'
+              % (mode, t * 1e3, R / t, t_eager / t, errs[mode]))
     # measured round 1: eager ~0.7-1.2 s/frame; HIP f16x3 ~0.13 s, f32 ~0.35 s
     assert t_eager / res['f16x3'] >= 4.0
     assert t_eager / res['f32'] >= 1.5

@@ -78,6 +78,48 @@ def test_network_gradients_match_reference(train_mode, operands, seeded_params, 
     print('gradients, training arithmetic', train_mode, 'operands', operands, '| vs reference', vs_ref, '| vs fp64', vs_exact)
 
 
+def test_f16_operand_gradients_equal_fp32_operand_gradients(seeded_params, golden_dir):
+    """the end-to-end bound above (6e-3, the problem's own noise) could not tell the default f16-operand
+    weight-gradient path from one ten times worse.  This does: the SAME process runs the step twice on the same inputs,
+    cfg.amd.train_operands = 'f16' (activations / dZ stored as f16, one f16 MFMA per product) and 'f32' (fp32 storage,
+    22-bit split operands).  Forward and dX chains are the same kernels with the same bits in both runs, so no ReLU or
+    voxel decision can flip between them: what differs is the operands' 11-bit rounding inside sums over 4 096
+    samples.  Every one of the 55 tensors must agree to 1e-3 in norm (measured: printed)."""
+    from humannerf_amd.config import cfg
+    from humannerf_amd.network import Network
+    with open(os.path.join(golden_dir, 'meta.json')) as f:
+        meta = json.load(f)['grad_s64']
+    g = np.load(os.path.join(golden_dir, 'grad_s64.npz'))
+    fr = grad_frame(meta)
+    keys = ['rays', 'near', 'far', 'dst_Rs', 'dst_Ts', 'cnl_gtfms', 'motion_weights_priors', 'dst_posevec',
+            'cnl_bbox_min_xyz', 'cnl_bbox_scale_xyz', 'bgcolor']
+    data = {k: torch.from_numpy(np.ascontiguousarray(fr[k])).to(dev()) for k in keys}
+    lw = torch.from_numpy(g['loss_weights']).to(dev())
+    cfg.N_samples, cfg.perturb, cfg.ignore_non_rigid_motions = meta['N_samples'], 0.0, False
+    grads = {}
+    try:
+        for operands in ('f16', 'f32'):
+            cfg.amd.train_operands = operands
+            net = Network()
+            net.load_state_dict({k: torch.from_numpy(v) for k, v in seeded_params.items()})
+            net = net.to(dev()).train()
+            out = net(**data, iter_val=meta['iter_val'])
+            reference_loss(out, lw).backward()
+            grads[operands] = {k: p.grad.double().cpu() for k, p in net.named_parameters() if p.grad is not None}
+            grads[operands + '_rgb'] = out['rgb'].detach().cpu()
+    finally:
+        cfg.N_samples, cfg.perturb, cfg.amd.train_operands = 128, 1.0, 'f16'
+    assert torch.equal(grads['f16_rgb'], grads['f32_rgb'])                   # same forward bits
+    assert set(grads['f16']) == set(grads['f32']) and len(grads['f16']) == 55
+    worst = (0.0, '')
+    for k, a in grads['f16'].items():
+        b = grads['f32'][k]
+        e = float((a - b).norm() / b.norm())
+        worst = max(worst, (e, k))
+        assert e <= 1e-3, (k, e)
+    print('f16 vs fp32 weight-gradient operands, end to end: worst tensor %.2e (%s)' % worst)
+
+
 def test_composite_bwd_kernel():
     from humannerf_amd import ops
     from oracle import oracle
@@ -358,7 +400,7 @@ def test_network_gradients_match_oracle_autograd_in_other_branches(seeded_params
     from humannerf_amd.config import cfg
     from humannerf_amd.network import Network
     from oracle import oracle
-    fr = scene.synthetic_frame(H=512, W=512, focal_at_512=1250.0, ray_stride=97)
+    fr = scene.synthetic_frame(H=512, W=512, focal_at_512=1250.0, ray_stride=29)       # ~270 rays x 64 samples
     R = fr['rays'].shape[1]
     rs = np.random.RandomState(3)
     lw = rs.standard_normal((R, 5)).astype(np.float32)
@@ -369,8 +411,10 @@ def test_network_gradients_match_oracle_autograd_in_other_branches(seeded_params
         kw['ignore_non_rigid_motions'] = True
     if t_rand is not None:
         kw['t_rand'] = torch.from_numpy(t_rand)
-    # fp64 oracle: with ~25 rays the fp32 evaluation noise of either side is ~2 % of a tensor's largest gradient element
-    # (scratch/grad_noise.py: the same in every arithmetic, exact fp32 MFMA included), so the comparator must be exact
+    # fp64 oracle as the comparator, and a few hundred rays (with ~25 rays the evaluation noise of a single
+    # ReLU / voxel-cell decision was ~2 % of a tensor's gradient and the bound had to be 5e-2: a 5 % error in one of
+    # these branches would have passed).  Bounds: the main gradient test's (6e-3 in norm / cosine 0.99998, 1e-2 /
+    # 0.99997 for the pose decoder); the worst tensor is printed.
     state = {k: torch.from_numpy(v).double().requires_grad_(True) for k, v in seeded_params.items()}
     ref_out = oracle.render(state, fr, dtype=torch.float64, **kw)
     ref_loss = reference_loss(ref_out, lw)
@@ -393,7 +437,7 @@ def test_network_gradients_match_oracle_autograd_in_other_branches(seeded_params
     finally:
         cfg.N_samples, cfg.perturb, cfg.ignore_non_rigid_motions = 128, 1.0, False
     assert abs(float(loss.detach()) - float(ref_loss.detach())) <= 2e-4 * max(1.0, abs(float(ref_loss.detach())))
-    checked = 0
+    checked, worst = 0, (0.0, 0.0, '')
     for name, p in net.named_parameters():
         ref = state[name].grad
         got = p.grad
@@ -401,9 +445,13 @@ def test_network_gradients_match_oracle_autograd_in_other_branches(seeded_params
             assert got is None or float(got.norm()) <= 1e-12, name
             continue
         g, r = got.double().cpu().reshape(-1), ref.double().reshape(-1)
-        assert abs(float(g.norm()) - float(r.norm())) <= 5e-2 * float(r.norm()), name
-        assert float(g @ r / (g.norm() * r.norm())) >= 0.999, name
+        e_norm = abs(float(g.norm()) - float(r.norm())) / float(r.norm())
+        e_cos = 1.0 - float(g @ r / (g.norm() * r.norm()))
+        worst = max(worst, (e_norm, e_cos, name))
+        lim_n, lim_c = (1e-2, 3e-5) if name.startswith('pose_decoder.') else (6e-3, 2e-5)
+        assert e_norm <= lim_n and e_cos <= lim_c, (name, e_norm, e_cos)
         checked += 1
+    print('other branches', variant, 'rays', R, 'worst tensor: norm err %.2e, 1 - cos %.2e (%s)' % worst)
     assert checked >= (40 if variant != 'tpose' else 26)
 
 

@@ -151,6 +151,58 @@ def test_train_loop_checkpoints_and_progress(tmp_path, seeded_params):
         cfg.N_samples, cfg.perturb, cfg.train.lossweights.lpips, cfg.train.log_interval = old
 
 
+def test_resume_from_a_reference_optimizer_checkpoint(tmp_path, seeded_params):
+    """a 'latest.tar' written by the REFERENCE's trainer (trainer.py:356-364) holds the state of a plain
+    torch.optim.Adam -- groups with ``fused`` None and CPU ``step`` tensors.  Loading it used to leave those in place and
+    the fused multi-tensor launch of GroupedAdam.step then met CPU step counters.  Written here with torch.optim.Adam on
+    the CPU exactly as the reference would (one group per tensor, optimizer.py:12-43), loaded, stepped: the moments
+    continue from the checkpoint (step 4 after 3 + 1), the update equals torch's own continuation."""
+    from humannerf_amd import scene
+    from humannerf_amd.config import cfg
+    from humannerf_amd.network import Network
+    from humannerf_amd.train import Trainer, customized_lr_names
+    dev = torch.device('cuda:0')
+    old = (cfg.N_samples, cfg.perturb, cfg.train.lossweights.lpips)
+    cfg.N_samples, cfg.train.lossweights.lpips = 32, 0.0
+    try:
+        ref_net = Network()
+        ref_net.load_state_dict({k: torch.from_numpy(v) for k, v in seeded_params.items()})
+        groups = []
+        for k, p in ref_net.named_parameters():
+            hit = [n for n in customized_lr_names() if n in k]
+            groups.append({'params': [p], 'lr': cfg.train['lr_' + hit[0]] if hit else cfg.train.lr, 'name': hit[0] if hit else k})
+        ref_opt = torch.optim.Adam(groups, lr=cfg.train.lr, betas=(0.9, 0.999))
+        g = torch.Generator().manual_seed(0)
+        for _ in range(3):                                   # three CPU steps on made-up gradients: non-trivial moments
+            for p in ref_net.parameters():
+                p.grad = torch.randn(p.shape, generator=g) * 1e-3
+            ref_opt.step()
+        sd = ref_opt.state_dict()
+        assert sd['param_groups'][0].get('fused') in (None, False) and not sd['state'][0]['step'].is_cuda
+        torch.save({'iter': 3, 'network': ref_net.state_dict(), 'optimizer': sd}, str(tmp_path / 'latest.tar'))
+
+        tr = Trainer(Network().to(dev), logdir=str(tmp_path))
+        tr.load_ckpt('latest')
+        assert tr.iter == 4
+        st = tr.optimizer.state
+        p0 = next(iter(tr.network.parameters()))
+        assert st[p0]['step'].is_cuda and st[p0]['step'].dtype == torch.float32 and float(st[p0]['step']) == 3.0
+        assert all(grp['fused'] for grp in tr.optimizer.param_groups)
+        # one more step on known gradients, on both sides
+        gs = [torch.randn(p.shape, generator=g) * 1e-3 for p in ref_net.parameters()]
+        for p, gr in zip(ref_net.parameters(), gs):
+            p.grad = gr.clone()
+        ref_opt.step()
+        for p, gr in zip(tr.network.parameters(), gs):
+            p.grad = gr.to(dev)
+        tr.optimizer.step()
+        assert float(st[p0]['step']) == 4.0
+        for (k, a), b in zip(tr.network.named_parameters(), ref_net.parameters()):
+            assert float((a.detach().cpu() - b.detach()).abs().max()) <= 1e-6 * max(1.0, float(b.abs().max())), k
+    finally:
+        cfg.N_samples, cfg.perturb, cfg.train.lossweights.lpips = old
+
+
 def test_operand_range_guard_raises_in_training(seeded_params):
     """the f16 / split-f16 training arithmetic assumes activations inside f16's useful range.  A network
     with a dead-small hidden layer (weights and bias ~1e-6) must not train silently on garbage weight gradients: the guard
