@@ -46,11 +46,42 @@ class GroupedAdam(torch.optim.Adam):
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
         super().__init__(params, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, fused=True)
 
+    def _compact_params(self):
+        """{index in the saved state: parameter} of the parameters that hold only the central taps of a reference
+        tensor (network._PointDeconv: ``hnrf_full_shape``)."""
+        out, idx = {}, 0
+        for group in self.param_groups:
+            for p in group['params']:
+                if getattr(p, 'hnrf_full_shape', None) is not None:
+                    out[idx] = p
+                idx += 1
+        return out
+
+    def state_dict(self):
+        """The reference's layout (trainer.py:356-364): moments of a compact parameter are written in the full tensor's
+        shape, zero outside the central taps -- which is what they are in the reference's own checkpoints."""
+        from .network import expand_central_taps
+        sd = super().state_dict()
+        for idx in self._compact_params():
+            st = sd['state'].get(idx)
+            if st:
+                sd['state'][idx] = dict(st, exp_avg=expand_central_taps(st['exp_avg']),
+                                        exp_avg_sq=expand_central_taps(st['exp_avg_sq']))
+        return sd
+
     def load_state_dict(self, state_dict):
         """Also accepts what the REFERENCE's optimizer wrote (trainer.py:356-364: a plain torch.optim.Adam -- groups with
         ``fused`` None / False and per-parameter ``step`` counters that are Python numbers or CPU tensors).  torch
         restores groups and step placement as saved; the fused multi-tensor launch of ``step`` needs every counter as a
         float32 scalar ON the parameter's device, and the groups marked fused."""
+        compact = self._compact_params()
+        if compact:
+            state_dict = dict(state_dict, state=dict(state_dict['state']))
+            for idx, p in compact.items():
+                st = state_dict['state'].get(idx)
+                if st and tuple(st['exp_avg'].shape) == tuple(p.hnrf_full_shape):
+                    state_dict['state'][idx] = dict(st, exp_avg=st['exp_avg'][:, :, 1:3, 1:3, 1:3].contiguous(),
+                                                    exp_avg_sq=st['exp_avg_sq'][:, :, 1:3, 1:3, 1:3].contiguous())
         super().load_state_dict(state_dict)
         for group in self.param_groups:
             group['fused'], group['foreach'] = True, False

@@ -17,7 +17,12 @@ def test_state_dict_contract():
     net = Network()
     sd = {k: tuple(v.shape) for k, v in net.state_dict().items()}
     assert sd == default_shapes()
-    assert sum(p.numel() for p in net.parameters()) == 64417381
+    assert sum(v.numel() for v in net.state_dict().values()) == 64417381
+    # ... of which the optimizer sees 35 057 253: the decoder's first transposed convolution (1x1x1 input) trains the central
+    # 2x2x2 of its 4x4x4 taps only -- the others never receive a gradient in the reference either (network._PointDeconv)
+    k0 = 'mweight_vol_decoder.decoder.block_conv.0.weight'
+    assert dict(net.named_parameters())[k0].shape == (1024, 512, 2, 2, 2)
+    assert sum(p.numel() for p in net.parameters()) == 64417381 - 1024 * 512 * 56
     # optimizer routes learning rates by these substrings (optimizer.py:9-34)
     names = [n for n, _ in net.named_parameters()]
     for sub in ('mweight_vol_decoder', 'pose_decoder', 'non_rigid_mlp', 'cnl_mlp'):
@@ -317,3 +322,71 @@ def test_f16_range_guard_schedule():
         cfg.amd.f16_range_guard = old
     assert ops._mode_arg('f16x3') == 1 and ops._mode_arg('f32') == 0
     assert ops._mode_arg('f16x3+noguard') == 0x101 and ops._mode_arg('f16x3+guard1:5') == 0x50201
+
+
+def test_point_deconv_keeps_the_reference_checkpoint_layout():
+    """network._PointDeconv: parameter = central taps, state_dict / optimizer checkpoints = the reference's full tensors.
+    The decoder's output equals F.conv_transpose3d on the full weight; the gradient of the compact parameter is the
+    central block of the full gradient and the rest of the full gradient is exactly zero (the premise); a round trip
+    through state_dict / GroupedAdam.state_dict changes nothing; Adam on the compact parameter moves the central taps
+    exactly as Adam on the full tensor does and leaves the other 56 taps where they were."""
+    import torch.nn.functional as F
+    from humannerf_amd.network import MotionWeightVolumeDecoder, expand_central_taps, full_gradient
+    from humannerf_amd.train import GroupedAdam
+    torch.manual_seed(3)
+    dec = MotionWeightVolumeDecoder(embedding_size=16, volume_size=8, total_bones=4)
+    first = dec.decoder.block_conv[0]
+    sd = dec.state_dict()
+    kw = 'decoder.block_conv.0.weight'
+    assert tuple(sd[kw].shape) == (1024, 512, 4, 4, 4) and tuple(first.weight.shape) == (1024, 512, 2, 2, 2)
+    assert 'decoder.block_conv.0.weight_rest' not in sd
+    pri = torch.rand(1, 5, 8, 8, 8) + 0.1
+    pri = pri / pri.sum(1, keepdim=True)
+    gout = torch.randn(1, 5, 8, 8, 8)
+    out = dec(motion_weights_priors=pri)
+    (out * gout).sum().backward()
+    # reference evaluation on the FULL tensors with torch's own transposed convolution
+    full = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    h = F.leaky_relu(F.linear(full['const_embedding'][None], full['decoder.block_mlp.0.weight'], full['decoder.block_mlp.0.bias']), 0.2)
+    h = h.view(-1, 1024, 1, 1, 1)
+    convs = sorted({int(k.split('.')[2]) for k in sd if k.startswith('decoder.block_conv.')})
+    for i in convs:
+        h = F.conv_transpose3d(h, full['decoder.block_conv.%d.weight' % i], full['decoder.block_conv.%d.bias' % i], stride=2, padding=1)
+        if i != convs[-1]:
+            h = F.leaky_relu(h, 0.2)
+    ref = F.softmax(h + torch.log(pri), dim=1)
+    assert (out - ref).abs().max() < 1e-6
+    (ref * gout).sum().backward()
+    gfull = full[kw].grad
+    outer = gfull.clone()
+    outer[:, :, 1:3, 1:3, 1:3] = 0
+    assert float(outer.abs().max()) == 0.0                                  # 56 of 64 taps: exactly zero, always
+    assert (full_gradient(first.weight) - gfull).abs().max() <= 1e-6 * float(gfull.abs().max())
+    # one Adam step on both sides, from the SAME gradient (Adam's first step is lr g / (|g| + eps): last-bit differences
+    # between two backward implementations would show wherever |g| ~ eps)
+    wfull = sd[kw].clone().requires_grad_(True)
+    wfull.grad = expand_central_taps(first.weight.grad)
+    torch.optim.Adam([wfull], lr=1e-2).step()
+    opt = GroupedAdam([{'params': [p]} for p in dec.parameters()], lr=1e-2)
+    if not torch.cuda.is_available():
+        for g in opt.param_groups:                                           # the fused launch needs a GPU: torch's loop here
+            g['fused'] = False
+        torch.optim.Adam.step(opt)
+    else:
+        opt.step()
+    after = dec.state_dict()
+    assert (after[kw] - wfull.detach()).abs().max() <= 1e-7
+    rest = after[kw].clone()
+    rest[:, :, 1:3, 1:3, 1:3] = sd[kw][:, :, 1:3, 1:3, 1:3]
+    assert torch.equal(rest, sd[kw])                                         # untouched taps: bit for bit
+    # checkpoints: moments in the reference's shape, zero outside the central taps; loading them back is the identity
+    osd = opt.state_dict()
+    idx = [n for n, _ in dec.named_parameters()].index(kw)
+    m = osd['state'][idx]['exp_avg']
+    assert tuple(m.shape) == (1024, 512, 4, 4, 4) and torch.equal(m, expand_central_taps(opt.state[first.weight]['exp_avg']))
+    opt2 = GroupedAdam([{'params': [p]} for p in dec.parameters()], lr=1e-2)
+    opt2.load_state_dict(osd)
+    assert torch.equal(opt2.state[first.weight]['exp_avg'], opt.state[first.weight]['exp_avg'])
+    dec2 = MotionWeightVolumeDecoder(embedding_size=16, volume_size=8, total_bones=4)
+    dec2.load_state_dict(after)
+    assert all(torch.equal(a, b) for a, b in zip(dec2.state_dict().values(), after.values()))
