@@ -57,6 +57,7 @@ SIGNATURES = {
     'hnrf_undistort_image': (_int, [_vp, _int, _int, _int, _vp, _vp, _int, _int, _vp, _vp]),
     'hnrf_composite_windows': (_int, [_vp, _vp, _int, _int, _vp, _int, _vp, _vp, _vp, _vp, _int, _int, _vp, _int, _int, _int, _vp, _vp]),
     'hnrf_resize_mask': (_int, [_vp, _int, _int, _int, _int, _vp, _vp, _vp, _vp, _int, _int, _vp, _vp]),
+    'hnrf_deconv_fold': (_int, [_vp, _vp, _int, _int, _int, _int, _vp, _vp]),
     'hnrf_render_workspace_bytes': (_sz, [_i64, _int]),
     'hnrf_render_frame_workspace_bytes': (_sz, [_i64, _int]),
     'hnrf_render_frame_fwd': (_int, [_vp] * 14 + [_int, ctypes.c_float, _i64, _int, _int, _int, _i64, _vp, _sz] + [_vp] * 11 + [_vp, _vp, _vp, _vp]),

@@ -17,7 +17,7 @@ static inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 using namespace hnrf;
 
-extern "C" int hnrf_abi_version(void) { return 12; }
+extern "C" int hnrf_abi_version(void) { return 13; }
 extern "C" const char* hnrf_last_error(void) { return g_err; }
 
 // workspace carve: z_vals[P] | mask[P] | x_skel[3P] | xyz[3P] | raw[4P] | idx[P] | count

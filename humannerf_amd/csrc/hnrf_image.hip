@@ -188,3 +188,54 @@ extern "C" int hnrf_resize_mask(const uint8_t* alpha, int Hs, int Ws, int channe
                        channel, mode, xofs, xw, yofs, yw, Hd, Wd, out);
     return check_launch("hnrf_resize_mask");
 }
+
+// ---- fold of a transposed 3-D convolution (kernel 4, stride 2, padding 1): the weight-volume decoder's layers
+// (core/utils/network_util.py:12-50: ConvTranspose3d stack of MotionWeightVolumeDecoder).  The GEMM col[i, (co, k)] =
+// sum_ci x[ci, i] W[ci, (co, k)] (one library GEMM on the weight's native layout, humannerf_amd/network.py) leaves, per
+// input voxel i = (d, h, w), the 4x4x4 block it adds to the output at (2d-1+kd, 2h-1+kh, 2w-1+kw); this kernel gathers,
+// per OUTPUT voxel, the 8 blocks that reach it (2 per axis) and adds the bias.  It is the adjoint of the pad + unfold
+// the backward GEMMs read through.  MIOpen's batch-1 transposed convolutions picked anything from a GEMM + col2im
+// (0.15 ms) to a grouped-convolution kernel (1.3 ms per training step) depending on the box's find results.
+namespace hnrf {
+__global__ __launch_bounds__(256) void deconv_fold_kernel(const float* __restrict__ col, const float* __restrict__ bias,
+                                                          int cout, int D, int H, int W, float* __restrict__ out) {
+    const int64_t n = (int64_t)cout * 8 * D * H * W;
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= n) return;
+    const int OW = 2 * W, OH = 2 * H, OD = 2 * D;
+    const int ow = (int)(t % OW), oh = (int)((t / OW) % OH), od = (int)((t / ((int64_t)OW * OH)) % OD);
+    const int co = (int)(t / ((int64_t)OW * OH * OD));
+    // per axis: output o gets taps (k, i) with 2 i - 1 + k = o: o even -> (1, o/2), (3, o/2 - 1); o odd -> (2, (o-1)/2), (0, (o+1)/2)
+    int kd[2], id[2], kh[2], ih[2], kw[2], iw[2];
+    kd[0] = (od & 1) ? 2 : 1; id[0] = od >> 1; kd[1] = (od & 1) ? 0 : 3; id[1] = (od & 1) ? (od >> 1) + 1 : (od >> 1) - 1;
+    kh[0] = (oh & 1) ? 2 : 1; ih[0] = oh >> 1; kh[1] = (oh & 1) ? 0 : 3; ih[1] = (oh & 1) ? (oh >> 1) + 1 : (oh >> 1) - 1;
+    kw[0] = (ow & 1) ? 2 : 1; iw[0] = ow >> 1; kw[1] = (ow & 1) ? 0 : 3; iw[1] = (ow & 1) ? (ow >> 1) + 1 : (ow >> 1) - 1;
+    float acc = bias ? bias[co] : 0.f;
+    const int64_t rs = (int64_t)cout * 64;
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+        if (id[a] < 0 || id[a] >= D) continue;
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            if (ih[b] < 0 || ih[b] >= H) continue;
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                if (iw[c] < 0 || iw[c] >= W) continue;
+                const int64_t i = ((int64_t)id[a] * H + ih[b]) * W + iw[c];
+                acc += col[i * rs + (int64_t)co * 64 + kd[a] * 16 + kh[b] * 4 + kw[c]];
+            }
+        }
+    }
+    out[t] = acc;
+}
+}  // namespace hnrf
+
+extern "C" int hnrf_deconv_fold(const float* col, const float* bias, int cout, int D, int H, int W, float* out, void* stream) {
+    HNRF_REQUIRE(col && out, HNRF_E_ARG, "hnrf_deconv_fold: null pointer");
+    HNRF_REQUIRE(cout > 0 && D > 0 && H > 0 && W > 0 && (int64_t)cout * 8 * D * H * W < (1LL << 40), HNRF_E_ARG,
+                 "hnrf_deconv_fold: bad dimensions");
+    const int64_t n = (int64_t)cout * 8 * D * H * W;
+    hipLaunchKernelGGL(deconv_fold_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, col, bias, cout,
+                       D, H, W, out);
+    return check_launch("hnrf_deconv_fold");
+}

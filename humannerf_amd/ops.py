@@ -758,3 +758,13 @@ def resize_mask(alpha, scale, channel=0):
         _lib.check(lib.hnrf_resize_mask(alpha.data_ptr(), Hs, Ws, channel, 1, xo.data_ptr(), xw.data_ptr(), yo.data_ptr(),
                                         yw.data_ptr(), Hd, Wd, out.data_ptr(), _stream()), 'hnrf_resize_mask')
     return out
+
+
+def deconv_fold(col, bias, cout, D, H, W):
+    """hnrf_deconv_fold: col (D*H*W, cout*64) fp32 -> (1, cout, 2D, 2H, 2W): the fold of ConvTranspose3d(4, 2, 1)."""
+    lib = _lib.load()
+    _chk(col, bias)
+    assert tuple(col.shape) == (D * H * W, cout * 64) and (bias is None or bias.numel() == cout)
+    out = torch.empty(1, cout, 2 * D, 2 * H, 2 * W, device=col.device)
+    _lib.check(lib.hnrf_deconv_fold(_ptr(col), _ptr(bias), cout, D, H, W, _ptr(out), _stream()), 'hnrf_deconv_fold')
+    return out

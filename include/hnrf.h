@@ -396,6 +396,14 @@ int hnrf_composite_windows(const uint8_t* orig, const uint8_t* alpha, int Hs, in
 int hnrf_resize_mask(const uint8_t* alpha, int Hs, int Ws, int channel, int mode, const int* xofs, const float* xw,
                      const int* yofs, const float* yw, int Hd, int Wd, float* out, void* stream);
 
+/* ---- weight-volume decoder glue (MotionWeightVolumeDecoder, mweight_vol_decoders/deconv_vol_decoder.py:25-33;
+ * ConvDecoder3D, core/utils/network_util.py:12-50) ----
+ * hnrf_deconv_fold: the scatter half of nn.ConvTranspose3d(kernel 4, stride 2, padding 1) on a batch-1 volume.
+ *  col [D*H*W, cout*64] = x^T W (one GEMM on the weight's native (cin, cout, 4,4,4) layout, done by the caller's BLAS),
+ *  bias [cout] or NULL -> out [cout, 2D, 2H, 2W]: out[co, 2d-1+kd, 2h-1+kh, 2w-1+kw] += col[(d,h,w), co*64 + kd*16+kh*4+kw],
+ *  written as a gather per output voxel (deterministic, no atomics). */
+int hnrf_deconv_fold(const float* col, const float* bias, int cout, int D, int H, int W, float* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

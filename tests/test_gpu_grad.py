@@ -719,3 +719,29 @@ def test_pose_mlp_kernels_match_fp64_autograd():
     b.square().sum().backward()
     for x1, x2 in zip(ga, [p.grad for p in ref.parameters()]):
         assert float((x1 - x2).abs().max()) <= 1e-5 * max(float(x2.abs().max()), 1e-30)
+
+
+def test_decoder_layers_as_gemm_plus_fold_kernel():
+    """network.conv_transpose3d_k4s2p1 on the GPU: one GEMM on the weight's native layout + hnrf_deconv_fold (the gather
+    form of the stride-2 scatter) against torch's own F.conv_transpose3d evaluated in fp64 on the CPU, forward and all
+    three gradients, for the decoder's layer shapes (network_util.py:30-42: 512->512 on 2^3, 512->256 on 4^3, 256->256
+    on 8^3, 256->25 on 16^3) and a ragged one."""
+    import torch.nn.functional as F
+    from humannerf_amd.network import conv_transpose3d_k4s2p1
+    torch.manual_seed(0)
+    for cin, cout, dims in ((512, 512, (2, 2, 2)), (512, 256, (4, 4, 4)), (256, 256, (8, 8, 8)), (256, 25, (16, 16, 16)),
+                            (7, 5, (3, 2, 4))):
+        x = torch.randn(1, cin, *dims)
+        w = torch.randn(cin, cout, 4, 4, 4) / np.sqrt(cin * 8.0)
+        b = torch.randn(cout)
+        g = torch.randn(1, cout, *[2 * d for d in dims])
+        ref_in = [t.double().requires_grad_(True) for t in (x, w, b)]
+        ref = F.conv_transpose3d(*ref_in, stride=2, padding=1)
+        ref_g = torch.autograd.grad(ref, ref_in, g.double())
+        got_in = [t.to(dev()).requires_grad_(True) for t in (x, w, b)]
+        got = conv_transpose3d_k4s2p1(*got_in)
+        got_g = torch.autograd.grad(got, got_in, g.to(dev()))
+        assert got.shape == ref.shape
+        assert float((got.cpu().double() - ref).abs().max()) <= 2e-5 * float(ref.abs().max())
+        for a, r in zip(got_g, ref_g):
+            assert float((a.cpu().double() - r).abs().max()) <= 2e-5 * float(r.abs().max()), (cin, cout, dims)

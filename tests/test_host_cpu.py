@@ -54,7 +54,7 @@ def test_abi_exports_every_declared_symbol():
     lib = _lib.load()
     for name in declared:
         assert hasattr(lib, name)
-    assert lib.hnrf_abi_version() == 12
+    assert lib.hnrf_abi_version() == 13
     assert lib.hnrf_canonical_packed_bytes(0) > 1 << 20
     assert lib.hnrf_render_workspace_bytes(4, 128) >= 4 * 128 * 44
 
