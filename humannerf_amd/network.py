@@ -131,7 +131,7 @@ class _CanonicalParams(nn.Module):
         return [m for m in self.pts_linears if isinstance(m, nn.Linear)] + [self.output_linear[0]]
 
 
-_POINT_CONV = True       # (A/B switch of the 1x1x1 special case, scratch/ab_pose.py)
+_POINT_CONV = True       # (A/B switch of the 1x1x1 special case, profiles/tools/ab_pose.py)
 
 
 class _ConvT3dK4S2P1(torch.autograd.Function):

@@ -1,6 +1,6 @@
 """Scratch: A/B of a switch inside the training step (same process, same box); currently the decoder's 1x1x1 layer."""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 from humannerf_amd import scene, network as N
 from humannerf_amd.config import cfg

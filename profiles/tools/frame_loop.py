@@ -1,6 +1,6 @@
 """Scratch: frame loop (render_frames over camera-only frames) against the pure render rate of the same box."""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 from humannerf_amd import scene
 import importlib

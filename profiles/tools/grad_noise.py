@@ -1,6 +1,6 @@
 """Scratch: element-wise gradient error of the training kernels vs the fp64 oracle, per operand mode."""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 from humannerf_amd import scene
 from humannerf_amd.config import cfg

@@ -1,6 +1,6 @@
 // Scratch: what does the matrix pipe ALONE cost in power?  Pure v_mfma_f32_32x32x16_f16 stream (3 independent
 // accumulators, operands = random f16 data rotating through 8 register sets, no LDS / VMEM in the loop), looped for
-// ~6 s so that rocm-smi can be polled next to it (scratch/power_probe.py does the same for the real kernel).
+// ~6 s so that rocm-smi can be polled next to it (profiles/tools/power_probe.py does the same for the real kernel).
 #include <hip/hip_runtime.h>
 #include <chrono>
 #include <cstdio>

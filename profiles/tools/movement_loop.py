@@ -1,9 +1,9 @@
 """run.run_movement (frames loaded WITH their images: PNG decode, undistortion, resize, SMPL helpers, device ray
 generation, render, unpack, metrics, PNG writer) against the pure render of the same frames' rays.
-    python scratch/movement_loop.py [n_frames] [lens]
+    python profiles/tools/movement_loop.py [n_frames] [lens]
 ``lens``: 1024x1024 PNGs with lens distortion, cfg.resize_img_scale = 0.5 (the ZJU-387 setting); rendered at 512x512."""
 import os, sys, tempfile, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 from humannerf_amd import dataset, ops, run, scene
 from humannerf_amd.config import cfg

@@ -1,6 +1,6 @@
 """Scratch: MFMA-busy fraction and clock under load per kernel from a rocprofv3 --pmc pass
 (GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_ANY).
-    python scratch/pmc_sq.py counter_collection.csv kernel_trace_or_'-' out.json substr [substr ...]"""
+    python profiles/tools/pmc_sq.py counter_collection.csv kernel_trace_or_'-' out.json substr [substr ...]"""
 import collections, csv, json, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 agg = collections.defaultdict(lambda: collections.defaultdict(list))

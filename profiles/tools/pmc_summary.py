@@ -1,4 +1,4 @@
-"""Scratch: per-kernel averages of rocprofv3 --pmc counter CSVs (python scratch/pmc_summary.py file.csv substring ...)."""
+"""Scratch: per-kernel averages of rocprofv3 --pmc counter CSVs (python profiles/tools/pmc_summary.py file.csv substring ...)."""
 import collections, csv, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 agg = collections.defaultdict(lambda: collections.defaultdict(list))

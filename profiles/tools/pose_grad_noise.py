@@ -1,12 +1,12 @@
 """Scratch: how much the pose-decoder gradient of the gradient-golden problem moves with last-bit changes of the forward."""
 import os, sys, json
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 from humannerf_amd.config import cfg
 from humannerf_amd import network as N
 from humannerf_amd.seeded import default_shapes, seeded_state
 from tests.test_grad_oracle import grad_frame, reference_loss
-gd = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tests', 'golden')
+gd = os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), 'tests', 'golden')
 meta = json.load(open(os.path.join(gd, 'meta.json')))['grad_s64']
 g = np.load(os.path.join(gd, 'grad_s64.npz'))
 fr = grad_frame(meta)

@@ -1,6 +1,6 @@
 """Scratch: sample rocm-smi power / clocks while the f16x3 canonical kernel runs back to back."""
 import os, subprocess, sys, threading, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 from humannerf_amd import ops
 from humannerf_amd.seeded import default_shapes, seeded_state

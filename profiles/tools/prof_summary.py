@@ -1,4 +1,4 @@
-"""Scratch: per-step kernel summary from a rocprofv3 rocpd database (python scratch/prof_summary.py db [steps])."""
+"""Scratch: per-step kernel summary from a rocprofv3 rocpd database (python profiles/tools/prof_summary.py db [steps])."""
 import collections, sqlite3, sys
 db = sqlite3.connect(sys.argv[1])
 nsteps = int(sys.argv[2]) if len(sys.argv) > 2 else 5

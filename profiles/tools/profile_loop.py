@@ -1,6 +1,6 @@
 """cProfile of the main thread of run.run_movement (which call of the frame loop blocks on the GPU?)."""
 import cProfile, io, os, pstats, sys, tempfile
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 from humannerf_amd import dataset, run, scene
 from humannerf_amd.config import cfg

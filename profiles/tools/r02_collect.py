@@ -1,7 +1,7 @@
 """Scratch: turn the round-2 rocprofv3 outputs under gpurun_out/ into the summaries committed under profiles/.
-    python scratch/r02_collect.py"""
+    python profiles/tools/r02_collect.py"""
 import collections, csv, glob, json, os, shutil
-R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+R = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 G, P = os.path.join(R, 'gpurun_out'), os.path.join(R, 'profiles')
 
 

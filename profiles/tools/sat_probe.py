@@ -1,6 +1,6 @@
 """f16-range guard probe: canonical / non-rigid inference kernels with one hidden layer scaled up; prints the status words."""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 from humannerf_amd import ops
 from humannerf_amd.seeded import default_shapes, seeded_state

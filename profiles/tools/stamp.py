@@ -1,6 +1,6 @@
-"""Scratch: read the diagnostic cycle stamps of the f16x3 canonical kernel (HNRF_LIB_PATH=scratch/libhnrf_stamp.so)."""
+"""Scratch: read the diagnostic cycle stamps of the f16x3 canonical kernel (HNRF_LIB_PATH=profiles/tools/libhnrf_stamp.so)."""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 from humannerf_amd import ops, _lib
 from humannerf_amd.seeded import default_shapes, seeded_state

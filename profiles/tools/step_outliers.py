@@ -1,6 +1,6 @@
-"""Scratch: host-side issue time of one training step (no synchronisation inside) against its GPU time."""
+"""Scratch: per-step wall times of 260 training steps (looking for periodic stalls)."""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 from humannerf_amd import scene, network as N
 from humannerf_amd.config import cfg
@@ -17,19 +17,13 @@ tb['target_rgbs'] = torch.rand(6144, 3, device=dev)
 cfg.perturb, cfg.N_samples, cfg.train.lossweights.lpips = 1.0, 128, 0.0
 net = N.Network(); net.load_state_dict({k: torch.from_numpy(v) for k, v in state.items()}); net = net.to(dev).train()
 tr = Trainer(net)
-for _ in range(5):
-    tr.train_step(tb)
-torch.cuda.synchronize()
-host = []
-for _ in range(20):
+import gc
+if os.environ.get("NOGC"): gc.freeze(); gc.disable()
+ts = []
+for i in range(260):
     torch.cuda.synchronize(); t0 = time.perf_counter()
     tr.train_step(tb)
-    host.append((time.perf_counter() - t0) * 1e3)
-    torch.cuda.synchronize()
-print('host issue time per step: median %.2f ms (min %.2f)' % (np.median(host), min(host)))
-import cProfile, pstats
-pr = cProfile.Profile(); pr.enable()
-for _ in range(10):
-    tr.train_step(tb)
-torch.cuda.synchronize(); pr.disable()
-pstats.Stats(pr).sort_stats('tottime').print_stats(18)
+    torch.cuda.synchronize(); ts.append((time.perf_counter() - t0) * 1e3)
+ts = np.array(ts)
+print('median %.2f ms; steps above 1.3x median:' % np.median(ts[5:]), [(i, round(float(t), 1)) for i, t in enumerate(ts) if i >= 5 and t > 1.3 * np.median(ts[5:])])
+print('reserved MB', torch.cuda.memory_reserved() / 2**20, 'allocated', torch.cuda.memory_allocated() / 2**20)

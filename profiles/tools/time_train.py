@@ -1,7 +1,7 @@
 """Scratch: wall-time split of one training iteration, per storage mode of the weight-gradient operands.
-    python scratch/time_train.py [f16|f32] [iters]"""
+    python profiles/tools/time_train.py [f16|f32] [iters]"""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 from humannerf_amd import scene
 from humannerf_amd.config import cfg

@@ -1,9 +1,9 @@
 """End-to-end training rate from a prepared subject directory (synthetic subject, 16 frames, rendered at 512x512):
 data side = dataset.FrameStream with the device-resident frame cache vs the numpy route.
-    python scratch/time_train_subject.py [iters] [lens]
+    python profiles/tools/time_train_subject.py [iters] [lens]
 ``lens``: 1024x1024 source PNGs with lens distortion and cfg.resize_img_scale = 0.5 (the ZJU-387 / wild setting)."""
 import os, sys, tempfile, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 from humannerf_amd import dataset, scene
 from humannerf_amd.config import cfg

@@ -37,7 +37,7 @@ def test_network_gradients_match_reference(train_mode, operands, seeded_params, 
         0.99998 is what can be asked against it;
       * vs that fp64 evaluation (torch.autograd through the oracle): 6e-3 / 0.99998 as well (1e-2 / 0.99997 for the pose
         decoder, which sits behind Rodrigues, the kinematic chain and the 2^9 positional-encoding band).  This problem's
-        gradient is not a smooth function of the forward's last bits: scratch/pose_grad_noise.py evaluates the SAME op
+        gradient is not a smooth function of the forward's last bits: profiles/tools/pose_grad_noise.py evaluates the SAME op
         sequence (torch GEMVs for the pose MLP, exact-fp32 kernels) twice, the second time with dst_posevec multiplied by
         1 + 1.2e-7, and the gradients move by 7.8e-3 (pose decoder), 4.5e-3 (canonical MLP, layer 0 bias), 3.2e-3
         (non-rigid MLP) -- one discrete decision (a ReLU / voxel cell / clamp of one of the 4 096 samples) flips.  Replacing

@@ -93,7 +93,7 @@ def test_optimizer_steps_match_oracle_adam(seeded_params):
         diff = np.abs(du - du_ref)
         assert diff.max() <= 2.05 * lr, (k, diff.max())                     # nobody moves further than a step apart
         # (fp32 evaluation noise of this 64-ray problem is ~2 % of a tensor's largest gradient element in EVERY arithmetic,
-        # the exact fp32 MFMA kernels included -- scratch/grad_noise.py -- so 'sure' means well above that)
+        # the exact fp32 MFMA kernels included -- profiles/tools/grad_noise.py -- so 'sure' means well above that)
         sure = (np.abs(g1[k]) > 0.1 * max(1e-30, np.abs(g1[k]).max())) & (np.abs(g1[k]) > 1e-6)
         if sure.any():
             worst = max(worst, (float(diff[sure].max() / lr), k))
