@@ -42,7 +42,7 @@ H = W = 512
 S = 128
 CNL_MAC_PER_SAMPLE = 492032
 NR_MAC_PER_SAMPLE = 100352           # row a11
-PMC_FILE = 'r02_pmc_canonical.json'
+PMC_FILE = 'r03_pmc_canonical.json'
 PEAK_TFLOPS = {'f32': 157.3, 'f16x3': 2500.0 / 3.0}   # MI355X_MICROARCH.md; f16x3 issues 3 f16 MFMAs per fp32-equivalent MAC
 
 
