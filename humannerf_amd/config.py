@@ -140,6 +140,9 @@ _DEFAULTS = {
         # which launches carry the guard (it costs 3 % of a frame): 'audit' = every ray chunk of the first frame after a
         # weight change, then one rotating chunk per frame | 'full' = every chunk of every frame | 'off'
         'f16_range_guard': 'audit',
+        # training items of dataset.FrameStream: patch positions drawn with the reference's exact calls on the global
+        # numpy generator (True: 4 ms of host time per item) or from a numpy Generator per item (False: 0.1 ms)
+        'exact_patch_draws': False,
         # materialise the per-sample diagnostic outputs the reference always
         # returns (backward_motion_weights, xyz_on_rays, ...; ~17 KB/ray).
         'diagnostics': True,

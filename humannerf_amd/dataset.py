@@ -429,13 +429,18 @@ class DeviceFrameCache:
                     self.bytes += ent['bytes']
         return ent
 
-    def train_batch(self, idx, bgcolor=None):
+    def train_batch(self, idx, bgcolor=None, rng=None):
+        """``rng`` None: the item's random choices come from the global numpy generator exactly like train_frame's (and
+        the reference's); a numpy Generator: from that (scene.PatchSampler.draw)."""
         import torch
         ent, dev = self.entry(idx), self.device
         # the two random draws of an item, in train_frame's order: background colour, then the patches
-        bg = (np.random.rand(3) * 255.).astype('float32') if bgcolor is None else np.array(bgcolor, dtype='float32')
+        if bgcolor is not None:
+            bg = np.array(bgcolor, dtype='float32')
+        else:
+            bg = ((np.random.rand(3) if rng is None else rng.random(3)) * 255.).astype('float32')
         sel, pinfo, div = ent['sampler'].draw(int(cfg.patch.N_patches), int(cfg.patch.size),
-                                              subject_ratio=float(cfg.patch.sample_subject_ratio))
+                                              subject_ratio=float(cfg.patch.sample_subject_ratio), rng=rng)
         # uploads through pinned memory: a pageable copy waits for everything queued on the stream (the training
         # step in flight) and would hold this loader thread for a whole step per tensor
         up = lambda a: torch.from_numpy(np.ascontiguousarray(a)).pin_memory().to(dev, non_blocking=True)
@@ -468,7 +473,7 @@ class FrameStream:
     through pinned memory so that they overlap the step that is running."""
 
     def __init__(self, subject, rank=0, world=1, seed=0, device=None, prefetch=3, workers=2, bgcolor=None,
-                 device_cache=None):
+                 device_cache=None, exact_draws=None):
         import threading
         import torch
         if device_cache is None:                      # default: frames stay resident on a GPU (DeviceFrameCache)
@@ -476,6 +481,9 @@ class FrameStream:
         self.cache = DeviceFrameCache(subject, device) if device_cache else None
         self.subject, self.rank, self.world, self.seed = subject, int(rank), int(world), int(seed)
         self.device, self.bgcolor = device, bgcolor
+        # cfg.amd.exact_patch_draws: patch positions from the reference's own calls on the global numpy generator (4 ms
+        # per item: choice(replace=False) shuffles every candidate pixel) instead of a Generator per item
+        self.exact_draws = bool(cfg.get('amd', {}).get('exact_patch_draws', False)) if exact_draws is None else bool(exact_draws)
         self._done = {}
         self._cv = threading.Condition()
         self._next_put, self._next_get, self._stop = 0, 0, False
@@ -508,8 +516,10 @@ class FrameStream:
             try:
                 if self.cache is not None:
                     import torch
+                    # the item's own generator, keyed by (seed, rank, ticket): the same items whatever the threads do
+                    rng = None if self.exact_draws else np.random.default_rng([self.seed, self.rank, ticket])
                     with torch.cuda.device(self.device):
-                        item = self.cache.train_batch(idx, bgcolor=self.bgcolor)
+                        item = self.cache.train_batch(idx, bgcolor=self.bgcolor, rng=rng)
                 else:
                     item = self.subject.train_frame(idx, bgcolor=self.bgcolor)
             except Exception as e:                                   # surfaced by __next__

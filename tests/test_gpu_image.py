@@ -92,3 +92,30 @@ def test_device_frame_cache_on_a_distorted_half_scale_subject(tmp_path):
         assert b['target_patches'].shape == (4, 16, 16, 3) and b['rays'].is_cuda
     finally:
         cfg.patch.N_patches, cfg.patch.size, cfg.resize_img_scale = old
+
+
+def test_frame_stream_items_do_not_depend_on_the_threads(tmp_path):
+    """FrameStream's default draws (cfg.amd.exact_patch_draws = False): every item has its own numpy Generator keyed by
+    (seed, rank, ticket), so the sequence of batches is the same whatever the number of worker threads and however they
+    interleave -- which the reference's global-generator draws, made from DataLoader workers, are not.  The exact draws
+    stay available (and are what test_device_frame_cache_* compare with the host route)."""
+    scene.write_synthetic_subject(str(tmp_path), n_frames=3, size=96)
+    subj = dataset.Subject(str(tmp_path))
+    old = (cfg.patch.N_patches, cfg.patch.size, cfg.get('resize_img_scale', 1.0))
+    cfg.patch.N_patches, cfg.patch.size, cfg.resize_img_scale = 3, 16, 1.0
+    try:
+        runs = []
+        for workers in (1, 3):
+            st = dataset.FrameStream(subj, device=DEV, seed=11, workers=workers, prefetch=4)
+            assert not st.exact_draws
+            runs.append([next(st) for _ in range(7)])
+            st.close()
+        for a, b in zip(*runs):
+            for k in ('rays', 'target_patches', 'patch_masks', 'bgcolor', 'near'):
+                assert torch.equal(a[k], b[k]), k
+        assert not torch.equal(runs[0][0]['bgcolor'], runs[0][1]['bgcolor'])         # random background per item (train.py:513-516)
+        other = dataset.FrameStream(subj, device=DEV, seed=12, workers=1)
+        assert not torch.equal(next(other)['bgcolor'], runs[0][0]['bgcolor'])
+        other.close()
+    finally:
+        cfg.patch.N_patches, cfg.patch.size, cfg.resize_img_scale = old
