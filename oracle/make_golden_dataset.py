@@ -9,7 +9,9 @@ tests/golden/subject_synth_expected.npz.
     python oracle/make_golden_dataset.py
 
 Not pinned (cv2 absent, see humannerf_amd/dataset.py): the Rodrigues step of apply_global_tfm_to_camera -- the
-extrinsics handed to the reference helpers here come from dataset.apply_global_tfm_to_camera.  No SMPL model is
+extrinsics handed to the reference helpers here come from dataset.apply_global_tfm_to_camera -- and the two image
+steps cv2.undistort / cv2.resize (humannerf_amd/imageproc.py; tests/test_image_cpu.py pins them by properties).  For a
+1024x1024 subject with lens distortion at resize_img_scale 0.5 the camera side IS pinned here ('lens/*').  No SMPL model is
 involved: joints are the synthetic skeleton of scene.py plus seeded noise."""
 import os
 import pickle
@@ -115,6 +117,31 @@ def main():
         expected[key + 'near'], expected[key + 'far'] = near[:, None].astype('float32'), far[:, None].astype('float32')
         expected[key + 'ray_mask'] = mask
         print('tpose', idx, 'rays', int(mask.sum()))
+    # ---- the ZJU-387 setting: 1024x1024 images with lens distortion, cfg.resize_img_scale = 0.5 (387/adventure.yaml:37).
+    # The directory itself is NOT committed (scene.write_synthetic_subject regenerates it from seeds in the tests: the
+    # two OpenCV steps cannot be run by the reference here, cv2 is absent); what the reference's helpers CAN pin is the
+    # camera side of such a frame -- intrinsics scaled by the resize factor (train.py:560), rays of the 512x512 image,
+    # bbox test -- stored as the packed hit mask and every 1024th kept ray.
+    import tempfile
+    lens_dir = tempfile.mkdtemp()
+    lens_names = scene.write_synthetic_subject(lens_dir, n_frames=1, size=1024, distortions=scene.ZJU_LIKE_DISTORTION, seed=5, radius=6.0)
+    with open(os.path.join(lens_dir, 'cameras.pkl'), 'rb') as f:
+        lcam = pickle.load(f)[lens_names[0]]
+    with open(os.path.join(lens_dir, 'mesh_infos.pkl'), 'rb') as f:
+        linfo = pickle.load(f)[lens_names[0]]
+    Kl = lcam['intrinsics'][:3, :3].copy()
+    Kl[:2] *= 0.5
+    El = dataset.apply_global_tfm_to_camera(lcam['extrinsics'], linfo['Rh'].astype('float32'), linfo['Th'].astype('float32'))
+    ro, rd = rc.get_rays_from_KRT(512, 512, Kl, El[:3, :3], El[:3, 3])
+    ro, rd = ro.reshape(-1, 3).copy(), rd.reshape(-1, 3).copy()
+    lbbox = {'min_xyz': linfo['joints'].min(0) - off, 'max_xyz': linfo['joints'].max(0) + off}
+    near, far, mask = rc.rays_intersect_3d_bbox(lbbox, ro, rd)
+    pick = np.arange(0, int(mask.sum()), 1024)
+    expected['lens/ray_mask_bits'] = np.packbits(mask)
+    expected['lens/pick'] = pick
+    expected['lens/rays_o'], expected['lens/rays_d'] = ro[mask][pick].astype('float32'), rd[mask][pick].astype('float32')
+    expected['lens/near'], expected['lens/far'] = near[pick].astype('float32'), far[pick].astype('float32')
+    print('lens frame: rays', int(mask.sum()), 'of', 512 * 512)
     np.savez_compressed(os.path.join(REPO, 'tests', 'golden', 'subject_synth_expected.npz'), **expected)
     # the loader must refuse anything that is not plain data
     evil = os.path.join(OUT, 'not_data.pkl')

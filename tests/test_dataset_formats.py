@@ -203,3 +203,53 @@ def test_frame_stream_shards_and_shuffles(subj):
     b = next(one)
     one.close()
     assert b['rays'].shape[0] == 3 and b['target_patches'].ndim == 4 and b['patch_masks'].dtype == bool
+
+
+def test_freeview_and_tpose_renders_use_the_configured_background(subj, monkeypatch):
+    """the reference builds every non-train dataset with bgcolor = cfg.bgcolor (create_dataset.py:40), so its
+    free-viewpoint and T-pose renders sit on the configured background ([0, 0, 0] in the ZJU yamls), not on the datasets'
+    white default.  run_freeview / run_tpose hand cfg.bgcolor to the frames they build."""
+    from humannerf_amd import run
+    from humannerf_amd.config import cfg
+    seen = {}
+
+    def fake_loop(network, frames, names, folder, logdir, rank, world, device, metrics=None):
+        seen[folder] = [frames[i]['bgcolor'].tolist() for i in (0, len(frames) - 1)]
+        return {}
+    monkeypatch.setattr(run, '_render_loop', fake_loop)
+    old = cfg.bgcolor
+    try:
+        cfg.bgcolor = [0., 0., 0.]
+        run.run_freeview(None, subj, frame_idx=0, total_frames=4, image_size=(H, W))
+        run.run_tpose(None, subj, total_frames=4, image_size=64)
+        assert seen['freeview_0'] == [[0., 0., 0.]] * 2 and seen['tpose'] == [[0., 0., 0.]] * 2
+        cfg.bgcolor = [255., 128., 0.]
+        run.run_freeview(None, subj, frame_idx=1, total_frames=4, image_size=(H, W))
+        assert seen['freeview_1'][0] == [255., 128., 0.]
+    finally:
+        cfg.bgcolor = old
+
+
+def test_half_scale_camera_matches_reference_helpers(want, tmp_path):
+    """The ZJU-387 setting (1024x1024 images, lens distortion, cfg.resize_img_scale = 0.5): the camera side of a frame --
+    intrinsics scaled by the resize factor (train.py:560), image size by cvRound, rays of the 512x512 image, bbox test --
+    against the reference's own numpy helpers (oracle/make_golden_dataset.py, 'lens/*': packed hit mask + every 1024th
+    kept ray).  The subject directory is regenerated from its seeds (scene.write_synthetic_subject); its image side is
+    what tests/test_image_cpu.py pins."""
+    from humannerf_amd import scene
+    from humannerf_amd.config import cfg
+    names = scene.write_synthetic_subject(str(tmp_path), n_frames=1, size=1024, distortions=scene.ZJU_LIKE_DISTORTION,
+                                          seed=5, radius=6.0)
+    s = dataset.Subject(str(tmp_path))
+    old = cfg.get('resize_img_scale', 1.0)
+    try:
+        cfg.resize_img_scale = 0.5
+        assert s.image_size(names[0]) == (512, 512)
+        fr = s.movement_frame(0, bgcolor=(0., 0., 0.), host_rays=True, image_size=s.image_size(names[0]))
+    finally:
+        cfg.resize_img_scale = old
+    mask = np.unpackbits(want['lens/ray_mask_bits'])[:512 * 512].astype(bool)
+    assert np.array_equal(fr['ray_mask'], mask) and 0.5 < mask.mean() < 0.99
+    pick = want['lens/pick']
+    assert np.array_equal(fr['rays'][0][pick], want['lens/rays_o']) and np.array_equal(fr['rays'][1][pick], want['lens/rays_d'])
+    assert np.array_equal(fr['near'][pick, 0], want['lens/near']) and np.array_equal(fr['far'][pick, 0], want['lens/far'])
