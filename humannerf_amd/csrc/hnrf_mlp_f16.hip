@@ -37,6 +37,21 @@ typedef _Float16 h16x2 __attribute__((ext_vector_type(2)));
 constexpr int RING = 3;                    // slabs resident in LDS
 constexpr float LO_SCALE = 2048.0f;        // 2^11
 constexpr float LO_INV = 1.0f / 2048.0f;
+// Forward images (inference and activation-saving kernels): the weights' low parts are stored UN-lifted, lo = f16(w - hi),
+// like the activations' (epi_pair_u), so that all three products of a k-step -- wh.xh, wh.xl, wl.xh -- go into ONE fp32
+// accumulator: no second accumulator (32 VGPRs), no `acc1 + acc2 / 2^11` in the epilogue (2 of its 8 VALU per value
+// pair), and the third MFMA multiplies tiny operands (the matrix pipe's energy depends on its operands' bits, and these
+// kernels run at the package power limit).  The price: w - hi ~ 2^-12 |w| sits in f16's subnormal range for |w| < 0.25,
+// so a weight is represented to max(2^-25, 2^-23 |w|) instead of 2^-23 |w| -- an ABSOLUTE floor of 3e-8 against layers
+// whose largest weights are 0.1 .. 0.3; a dot product over 256 activations of order 0.5 sees 1.4e-7 of it, below the
+// 6e-7 of fp32 accumulation itself (measured: tests/test_gpu_parity.py -s).  Layers with abnormally small weights are
+// lifted as a whole by an exact power of two (layer_exponent), as before.  The dX chains keep the lifted form.
+// -DHNRF_WLO_LIFTED builds the round-2 scheme (two accumulators) for A/B through HNRF_LIB_PATH.
+#ifdef HNRF_WLO_LIFTED
+constexpr bool WLO_UNLIFTED = false;
+#else
+constexpr bool WLO_UNLIFTED = true;
+#endif
 
 enum { PE16_NONE = 0, PE16_CANONICAL = 1, PE16_NONRIGID = 2 };
 
@@ -147,7 +162,7 @@ __global__ void pack_layer16_kernel(PackSet16 set, const float* __restrict__ con
         float w = 0.f;
         if (row < d.n_out && col >= 0 && col < d.n_in) w = ldexpf(d.W[(int64_t)row * d.n_in + col], kexp);
         const _Float16 hi = (_Float16)w;
-        const _Float16 lo = (_Float16)((w - (float)hi) * LO_SCALE);
+        const _Float16 lo = WLO_UNLIFTED ? (_Float16)(w - (float)hi) : (_Float16)((w - (float)hi) * LO_SCALE);
         outv[e] = part ? lo : hi;
     }
     *reinterpret_cast<h16x2*>(dst) = h16x2{outv[0], outv[1]};
@@ -338,8 +353,8 @@ __device__ __forceinline__ void raise_f16_range(const char* packed, int64_t off,
 template <bool RELU>
 __device__ __forceinline__ void epi_pair_u(const f32x16& a1, const f32x16& a2, int i, h16x8& hi, h16x8& lo,
                                            unsigned long long& sflag, bool guard) {
-    float x0 = fmaf(a2[2 * i], LO_INV, a1[2 * i]);
-    float x1 = fmaf(a2[2 * i + 1], LO_INV, a1[2 * i + 1]);
+    float x0 = WLO_UNLIFTED ? a1[2 * i] : fmaf(a2[2 * i], LO_INV, a1[2 * i]);
+    float x1 = WLO_UNLIFTED ? a1[2 * i + 1] : fmaf(a2[2 * i + 1], LO_INV, a1[2 * i + 1]);
     if (RELU) {
         x0 = __builtin_amdgcn_fmed3f(x0, 0.f, 65504.f);
         x1 = __builtin_amdgcn_fmed3f(x1, 0.f, 65504.f);
@@ -376,8 +391,8 @@ __device__ __forceinline__ void split8_u(const float (&v)[8], h16x8& hi, h16x8& 
 template <bool RELU, bool ULO = false>
 __device__ __forceinline__ h16x2 epi_pair_x(const f32x16& a1, const f32x16& a2, int i, h16x8& hi, h16x8& lo, float& x0o,
                                             float& x1o) {
-    float x0 = fmaf(a2[2 * i], LO_INV, a1[2 * i]);
-    float x1 = fmaf(a2[2 * i + 1], LO_INV, a1[2 * i + 1]);
+    float x0 = (ULO && WLO_UNLIFTED) ? a1[2 * i] : fmaf(a2[2 * i], LO_INV, a1[2 * i]);
+    float x1 = (ULO && WLO_UNLIFTED) ? a1[2 * i + 1] : fmaf(a2[2 * i + 1], LO_INV, a1[2 * i + 1]);
     if (RELU) {
         x0 = __builtin_amdgcn_fmed3f(x0, 0.f, 65504.f);
         x1 = __builtin_amdgcn_fmed3f(x1, 0.f, 65504.f);
@@ -635,7 +650,8 @@ __device__ __forceinline__ void layer16(Pipe& p, int nb1, int nb2, h16x8 (&bh)[N
                 acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, xh, acc1, 0, 0, 0);
                 if (ULO) acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, xl, acc1, 0, 0, 0);
                 else acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, xl, acc2, 0, 0, 0);
-                acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, xh, acc2, 0, 0, 0);
+                if (ULO && WLO_UNLIFTED) acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, xh, acc1, 0, 0, 0);
+                else acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, xh, acc2, 0, 0, 0);
                 if (NT > 1 && sv_has_bias(SAVE) && ks == NK - 1 && t + 1 < NT) {
                     const unsigned bn = p.lds_base + p.bias_off + (tt + 1) * 128 + (lane >> 5) * 16;   // (tt + 1 == TPS: next slab's first)
                     const f32x4 b0 = lds_ld4f(bn), b1 = lds_ld4f(bn + 32), b2 = lds_ld4f(bn + 64), b3 = lds_ld4f(bn + 96);
@@ -726,7 +742,7 @@ __device__ __forceinline__ void layer16(Pipe& p, int nb1, int nb2, h16x8 (&bh)[N
     }
     if (NT == 1) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) last[r] = pacc1[r] + pacc2[r] * LO_INV;
+        for (int r = 0; r < 16; ++r) last[r] = (ULO && WLO_UNLIFTED) ? pacc1[r] : pacc1[r] + pacc2[r] * LO_INV;
     } else if (DEFER) {
         *pend1 = pacc1;
         *pend2 = pacc2;
@@ -850,7 +866,8 @@ __device__ __forceinline__ void layer16x2(Pipe& p, unsigned stash_per_wave, int 
                 for (int g = 0; g < 2; ++g) {
                     acc1[g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, xh[g], acc1[g], 0, 0, 0);
                     acc1[g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, xl[g], acc1[g], 0, 0, 0);     // (xl un-scaled: epi_pair_u)
-                    acc2[g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, xh[g], acc2[g], 0, 0, 0);
+                    if (WLO_UNLIFTED) acc1[g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, xh[g], acc1[g], 0, 0, 0);
+                    else acc2[g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, xh[g], acc2[g], 0, 0, 0);
                 }
                 {
                     constexpr int MAXP = (TPS * NK - 1) < 10 ? (TPS * NK - 1) : 10;
@@ -900,7 +917,7 @@ __device__ __forceinline__ void layer16x2(Pipe& p, unsigned stash_per_wave, int 
     for (int g = 0; g < 2; ++g) {
         if (NT == 1) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) last[g][r] = pacc1[g][r] + pacc2[g][r] * LO_INV;
+            for (int r = 0; r < 16; ++r) last[g][r] = WLO_UNLIFTED ? pacc1[g][r] : pacc1[g][r] + pacc2[g][r] * LO_INV;
         } else {
 #pragma unroll
             for (int i = 0; i < 8; ++i)
@@ -1298,7 +1315,7 @@ __global__ void pack_bwd16_kernel(PackBwdSet16 set, char* __restrict__ packed) {
         float w = 0.f;
         if (o >= 0 && o < d.n_out && col >= 0 && col < d.n_in) w = ldexpf(d.W[(int64_t)o * d.n_in + col], kexp);
         const _Float16 hi = (_Float16)w;
-        const _Float16 lo = (_Float16)((w - (float)hi) * LO_SCALE);
+        const _Float16 lo = (_Float16)((w - (float)hi) * LO_SCALE);      // (the dX chains keep the lifted form)
         outv[e] = part ? lo : hi;
     }
     *reinterpret_cast<h16x2*>(packed + d.off + ((int64_t)t * slab_units + u) * 4) = h16x2{outv[0], outv[1]};
