@@ -715,6 +715,17 @@ class Network(nn.Module):
         else:
             t_rand = None
         diag = bool(amd_option('diagnostics', True))
+        if N == 0:
+            # a camera that does not see the subject's bbox (the reference's chunk loop, network.py:330-352, has nothing
+            # to concatenate then and raises; a render loop should get its background image): the 11 keys, empty
+            shp = {'rgb': (3,), 'alpha': (), 'depth': ()}
+            if diag or train_path:
+                shp.update(weights_on_rays=(S,), rgb_on_rays=(S, 3), cnl_xyz=(3,), cnl_rgb=(3,), cnl_weight=(),
+                           xyz_on_rays=(S, 3), backward_motion_weights=(S, self.total_bones), offsets=(S, 3))
+            zero = sum(p.sum() for p in self.parameters() if p.requires_grad) * 0.0 if train_path else None
+            out = {k: torch.zeros((0,) + v, device=dev) + (zero if zero is not None and k in ('rgb', 'alpha', 'depth') else 0.0)
+                   for k, v in shp.items()}
+            return {k: v.reshape(list(rays_shape[:-1]) + list(v.shape[1:])) for k, v in out.items()}
 
         term_eps = float(amd_option('term_eps', 0.0))
         if not train_path and term_eps == 0.0:

@@ -777,3 +777,35 @@ def test_device_frame_cache_equals_host_route(golden_dir):
         assert len(cache.entries) == 3 and cache.bytes > 0
     finally:
         cfg.patch.N_patches, cfg.patch.size = old
+
+
+def test_frames_without_rays_render_as_background(gpu_net):
+    """A camera that does not see the subject's bbox yields zero rays.  The reference's chunk loop (network.py:330-352)
+    has nothing to concatenate then and raises; here Network.forward returns its keys empty and the render loop delivers
+    the background image -- on both output paths, between ordinary frames."""
+    from humannerf_amd import render, scene
+    from humannerf_amd.config import cfg
+    cams = [scene.synthetic_frame(H=64, W=64, focal_at_512=1250.0, pose_seed=i, camera_only=True, bgcolor=(30., 60., 90.))
+            for i in range(3)]
+    E = cams[1]['E'].copy()
+    E[:3, 3] += np.array([50., 0., 0.], dtype=np.float32)
+    cams[1] = dict(cams[1], E=E)
+    old = (cfg.N_samples, cfg.perturb, cfg.amd.diagnostics)
+    cfg.N_samples, cfg.perturb = 64, 0.
+    try:
+        for diag in (True, False):
+            cfg.amd.diagnostics = diag
+            imgs = render.render_frames(gpu_net, cams, device=dev())
+            assert sorted(imgs) == [0, 1, 2] and imgs[1].shape == (64, 64, 3)
+            assert (imgs[1] == np.array([30, 60, 90], dtype=np.uint8)).all()            # background only
+            assert (imgs[0] != imgs[1]).any() and (imgs[2] != imgs[1]).any()
+        fr = scene.synthetic_frame(H=64, W=64, focal_at_512=1250.0)
+        data = frame_to_gpu(fr)
+        data['rays'], data['near'], data['far'] = data['rays'][:, :0].contiguous(), data['near'][:0].contiguous(), data['far'][:0].contiguous()
+        cfg.amd.diagnostics = True
+        with torch.no_grad():
+            out = gpu_net(**data, iter_val=1e7)
+        assert len(out) == 11 and out['rgb'].shape == (0, 3) and out['weights_on_rays'].shape == (0, 64)
+        assert out['backward_motion_weights'].shape == (0, 64, 24)
+    finally:
+        cfg.N_samples, cfg.perturb, cfg.amd.diagnostics = old
