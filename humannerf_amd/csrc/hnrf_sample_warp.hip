@@ -60,8 +60,15 @@ __global__ __launch_bounds__(256) void sample_warp_kernel(
     const int GG = G * G;
 
     float wsum = 0.f, ax = 0.f, ay = 0.f, az = 0.f;
-#pragma unroll 4
-    for (int b = 0; b < B; ++b) {
+    // four bones per trip (their 16 gathers in flight together); the diagnostic per-bone weights leave as one 16-byte
+    // store per trip instead of four 4-byte stores at a 96-byte stride between lanes
+    const bool bmw4 = WRITE_BMW && (B & 3) == 0;
+    for (int b0 = 0; b0 < B; b0 += 4) {
+    float w4[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int b = b0 + j;
+        if (b >= B) break;
         const float* Rb = Rs + b * 9;   // wave-uniform address: scalar loads
         const float* Tb = Ts + b * 3;
         const float qx = Rb[0] * px + Rb[1] * py + Rb[2] * pz + Tb[0];
@@ -109,7 +116,10 @@ __global__ __launch_bounds__(256) void sample_warp_kernel(
         ax += w * qx;
         ay += w * qy;
         az += w * qz;
-        if (WRITE_BMW) bmw[p * B + b] = w;
+        w4[j] = w;
+        if (WRITE_BMW && !bmw4) bmw[p * B + b] = w;
+    }
+    if (bmw4) *reinterpret_cast<float4*>(bmw + p * B + b0) = make_float4(w4[0], w4[1], w4[2], w4[3]);
     }
     const float den = fmaxf(wsum, 0.0001f);
     z_vals[p] = z;
