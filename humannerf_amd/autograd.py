@@ -93,7 +93,9 @@ class OperandRangeGuard:
             if dz is not None and dz.dtype == torch.float16:
                 large = large | (layer_amax(dz) >= ACT_MAX).any()
         fin = torch.isfinite(d_in).all()
-        return torch.stack([(amax < ACT_MIN).any(), large, ~fin])
+        # (a layer whose activations are ALL exactly zero -- a ReLU layer fed zeros with zero biases, as at the start of a
+        # run -- has nothing to lose in f16)
+        return torch.stack([((amax < ACT_MIN) & (amax > 0)).any(), large, ~fin])
 
     def due(self):
         every = int(amd_option('train_check_every', 200))
@@ -153,7 +155,11 @@ class RenderRays(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, rays_o, rays_d, near, far, t_rand, bbox_min, bbox_scale, hann_w, cond, bg, n_samples,
-                use_nonrigid, diag, motion_Rs, motion_Ts, vol, *params):
+                use_nonrigid, diag, const_offset, motion_Rs, motion_Ts, vol, *params):
+        """``const_offset`` (3,) or None: the non-rigid offset when it is ONE vector for the whole frame -- before
+        non_rigid_motion_mlp.kick_in_iter the condition code and every Hann weight are zero (network.py:735-737,
+        hannw_fourier.py:28-40), so the MLP sees zeros at every sample and returns MLP(0).  The caller evaluates that once
+        (differentiably, in fp32) and passes ``use_nonrigid = False``: xyz = x_skel + const_offset."""
         nr_w, nr_b = list(params[0:7]), list(params[7:14])
         cn_w, cn_b = list(params[14:23]), list(params[23:32])
         motion_Rs, motion_Ts, vol = motion_Rs.contiguous(), motion_Ts.contiguous(), vol.contiguous()
@@ -164,6 +170,9 @@ class RenderRays(torch.autograd.Function):
         if use_nonrigid:
             nr_packed = ops.nonrigid_pack(nr_w, nr_b, cond, mode)
             xyz, offsets, pe_n, acts_n, bits_n = ops.nonrigid_train(x_skel, hann_w, nr_packed, tmode)
+        elif const_offset is not None:
+            xyz, pe_n, acts_n, bits_n = (x_skel + const_offset.detach().reshape(1, 1, 3)).contiguous(), None, None, None
+            offsets = const_offset.detach().reshape(1, 1, 3).expand_as(x_skel).contiguous() if diag else None
         else:
             xyz, pe_n, acts_n, bits_n = x_skel, None, None, None
             offsets = torch.zeros_like(x_skel) if diag else None            # network.py:276-277
@@ -171,6 +180,7 @@ class RenderRays(torch.autograd.Function):
         raw, pe_c, acts_c, bits_c = ops.canonical_train(xyz, cn_packed, tmode)
         out = ops.composite(raw, mask, z, rays_d, xyz if diag else None, bg, diagnostics=bool(diag))
         ctx.use_nonrigid = use_nonrigid
+        ctx.const_offset = const_offset is not None
         ctx.half = half
         ctx.n_out = 11 if diag else 3
         ctx.save_for_backward(rays_o, rays_d, z, x_skel, mask, xyz, raw, pe_c, acts_c, pe_n, acts_n, motion_Rs,
@@ -228,4 +238,5 @@ class RenderRays(torch.autograd.Function):
         del dZc_keep, dZn_keep
         d_vol, d_Rs, d_Ts = ops.sample_warp_bwd(rays_o, rays_d, z, motion_Rs, motion_Ts, vol, bbox_min, bbox_scale,
                                                 x_skel, mask, d_x_skel.view_as(x_skel).contiguous(), d_mask)
-        return (None,) * 13 + (d_Rs, d_Ts, d_vol, *gWn, *gbn, *gWc, *gbc)
+        d_offset = d_xyz.reshape(P, 3).sum(dim=0) if ctx.const_offset else None
+        return (None,) * 13 + (d_offset, d_Rs, d_Ts, d_vol, *gWn, *gbn, *gWc, *gbc)

@@ -687,8 +687,10 @@ class Network(nn.Module):
 
         mode = self._mlp_mode()
         nr_packed, cnl_packed, hann_w = None, None, None
+        self._nr_inputs_are_zero = False
         if not ignore_nr:
             hann_w = hann_window_weights(iter_val, nr_cfg.multires, nr_cfg.kick_in_iter, nr_cfg.full_band_iter)
+            self._nr_inputs_are_zero = iter_val < nr_cfg.kick_in_iter and float(hann_w.abs().max()) == 0.0
             # through pinned memory: a pageable host-to-device copy waits for everything queued on the stream, i.e. it
             # would synchronise host and GPU once per training step / frame
             hann_w = hann_w.pin_memory().to(dev, non_blocking=True) if dev.type == 'cuda' else hann_w.to(dev)
@@ -764,6 +766,17 @@ class Network(nn.Module):
         lead = list(rays_shape[:-1])
         return {k: v.reshape(lead + list(v.shape[1:])) for k, v in out.items()}
 
+    def _nonrigid_of_zero(self):
+        """NonRigidMotionMLP.forward (mlp_offset.py:74-114) on an all-zero input row: (3,), differentiable."""
+        lin = self.non_rigid_mlp.module.linears()
+        h = lin[0].bias                                             # W0 @ 0 + b0
+        for i, l in enumerate(lin[1:-1], start=1):
+            h = torch.relu(h)
+            if l.in_features != h.shape[0]:                         # the skip layer takes [h | PE36], and the PE is zero too
+                h = torch.cat([h, h.new_zeros(l.in_features - h.shape[0])])
+            h = F.linear(h, l.weight, l.bias)
+        return F.linear(torch.relu(h), lin[-1].weight, lin[-1].bias)
+
     def _render_rays_train(self, rays_o, rays_d, near, far, t_rand, motion_Rs, motion_Ts, vol, bbox_min, bbox_scale,
                            hann_w, cond, bg, S, use_nonrigid, diag):
         """Differentiable chunk: autograd.RenderRays (activation-saving MLP kernels).  rgb / alpha / depth carry
@@ -774,8 +787,18 @@ class Network(nn.Module):
         if hann_w is None:
             hann_w = torch.ones(6, device=rays_o.device)
         params = [l.weight for l in nr] + [l.bias for l in nr] + [l.weight for l in cn] + [l.bias for l in cn]
+        const_offset = None
+        if use_nonrigid and getattr(self, '_nr_inputs_are_zero', False):
+            # before non_rigid_motion_mlp.kick_in_iter the MLP is fed zeros at every sample (condition code x 0,
+            # network.py:735-737; Hann weights all 0, hannw_fourier.py:28-40): its offset is the per-frame constant MLP(0)
+            # (SURVEY section 7).  Evaluated once, in fp32 with torch's autograd, instead of 786 432 times: the first
+            # 10 000 (ZJU) / 100 000 (wild) iterations of a run lose the non-rigid kernels' forward, chain and weight
+            # gradients (1.9 of 10 ms), and their near-zero activations never meet the f16 operand range.
+            const_offset = self._nonrigid_of_zero()
+            use_nonrigid = False
         res = RenderRays.apply(rays_o, rays_d, near, far, t_rand, bbox_min, bbox_scale, hann_w,
-                               cond.detach().contiguous(), bg, S, use_nonrigid, diag, motion_Rs, motion_Ts, vol, *params)
+                               cond.detach().contiguous(), bg, S, use_nonrigid, diag, const_offset, motion_Rs, motion_Ts, vol,
+                               *params)
         return dict(zip(RenderRays.OUTPUT_KEYS if diag else RenderRays.OUTPUT_KEYS[:3], res))
 
     def _render_rays(self, rays_o, rays_d, near, far, t_rand, motion_Rs, motion_Ts, vol, bbox_min, bbox_scale,
