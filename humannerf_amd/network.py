@@ -769,7 +769,10 @@ class Network(nn.Module):
     def _nonrigid_of_zero(self):
         """NonRigidMotionMLP.forward (mlp_offset.py:74-114) on an all-zero input row: (3,), differentiable."""
         lin = self.non_rigid_mlp.module.linears()
-        h = lin[0].bias                                             # W0 @ 0 + b0
+        # (through F.linear although W0 @ 0 = 0: W0 must receive its all-zero gradient like in the reference, so that Adam
+        # creates its state and counts its steps from the first iteration -- a None gradient would restart the bias
+        # correction of W0 at the kick-in iteration)
+        h = F.linear(lin[0].weight.new_zeros(lin[0].in_features), lin[0].weight, lin[0].bias)
         for i, l in enumerate(lin[1:-1], start=1):
             h = torch.relu(h)
             if l.in_features != h.shape[0]:                         # the skip layer takes [h | PE36], and the PE is zero too

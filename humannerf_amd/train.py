@@ -121,6 +121,13 @@ class GroupedAdam(torch.optim.Adam):
             torch._foreach_add_(steps, 1)
             torch._fused_adam_(ps, gs, m, v, [], steps, amsgrad=False, lr=lr, beta1=b1, beta2=b2, weight_decay=wd,
                                eps=eps, maximize=False, grad_scale=None, found_inf=None)
+            # torch._fused_adam_ called directly does NOT advance the parameters' version counters (the optimizer wrapper's
+            # bookkeeping is what normally does) -- and the network's packed-weight and weight-volume caches are keyed by
+            # them: without this an eval render after training steps (Trainer's progress mosaics, a render at the end of a
+            # run) silently used the weights of before.  An in-place no-op on an empty view bumps the shared counter
+            # without a launch.
+            for p in ps:
+                p.detach().reshape(-1)[:0].zero_()
 
 
 def build_optimizer(network):

@@ -151,6 +151,49 @@ def test_train_loop_checkpoints_and_progress(tmp_path, seeded_params):
         cfg.N_samples, cfg.perturb, cfg.train.lossweights.lpips, cfg.train.log_interval = old
 
 
+def test_render_after_training_steps_uses_the_new_weights(seeded_params):
+    """The inference side caches the packed weight images and the decoded weight volume, keyed by the parameters' version
+    counters.  Round 3 found the fused Adam launch of GroupedAdam.step leaving those counters alone: an eval render after
+    training steps in the same process -- Trainer's progress mosaics, a render at the end of a run -- silently used the
+    weights of before.  Here: render, take training steps, render again (different image), then compare with a FRESH
+    network loaded from the trained state_dict (same image, bit for bit)."""
+    from humannerf_amd import scene
+    from humannerf_amd.config import cfg
+    from humannerf_amd.network import Network
+    from humannerf_amd.train import Trainer
+    dev = torch.device('cuda:0')
+    fr = scene.synthetic_frame(H=512, W=512, focal_at_512=1250.0, ray_stride=61)
+    R = fr['rays'].shape[1]
+    old = (cfg.N_samples, cfg.perturb, cfg.train.lossweights.lpips, cfg.amd.diagnostics)
+    cfg.N_samples, cfg.train.lossweights.lpips, cfg.amd.diagnostics = 32, 0.0, False
+    try:
+        net = Network()
+        net.load_state_dict({k: torch.from_numpy(v) for k, v in seeded_params.items()})
+        net = net.to(dev)
+        batch = {k: torch.from_numpy(np.ascontiguousarray(fr[k])).to(dev) for k in KEYS}
+
+        def render(n):
+            n.eval()
+            cfg.perturb = 0.
+            with torch.no_grad():
+                return n(**batch, iter_val=1e7)['rgb'].clone()
+        before = render(net)
+        net.train()
+        tr = Trainer(net)
+        tr.iter = 30000
+        cfg.perturb = 1.0
+        tb = dict(batch, target_rgbs=torch.rand(R, 3, device=dev))
+        for _ in range(3):
+            tr.train_step(tb)
+        after = render(net)
+        assert float((after - before).abs().max()) > 1e-4
+        fresh = Network()
+        fresh.load_state_dict(net.state_dict())
+        assert torch.equal(render(fresh.to(dev)), after)
+    finally:
+        cfg.N_samples, cfg.perturb, cfg.train.lossweights.lpips, cfg.amd.diagnostics = old
+
+
 def test_resume_from_a_reference_optimizer_checkpoint(tmp_path, seeded_params):
     """a 'latest.tar' written by the REFERENCE's trainer (trainer.py:356-364) holds the state of a plain
     torch.optim.Adam -- groups with ``fused`` None and CPU ``step`` tensors.  Loading it used to leave those in place and

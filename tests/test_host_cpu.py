@@ -219,6 +219,9 @@ def test_grouped_adam_is_torch_adam_with_fewer_launches():
         gb.step()
     for x, y in zip(a, b):
         assert (x - y).abs().max() <= 1e-7
+    # every stepped parameter's version counter moved with every step: the network's packed-weight / weight-volume caches
+    # are keyed by it (torch._fused_adam_ alone leaves it where it was: renders after training used stale weights)
+    assert a[0]._version >= 6 and a[1]._version >= 5 and a[2]._version >= 6
     sd = ga.state_dict()
     assert float(sd['state'][0]['step']) == 6.0 and float(sd['state'][1]['step']) == 5.0
     assert [g['name'] for g in sd['param_groups']] == ['x', 'y', 'z']
