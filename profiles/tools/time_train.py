@@ -27,10 +27,12 @@ tb = dict(data); tb['rays'] = data['rays'][:, idx].contiguous(); tb['near'] = da
 tgt = torch.rand(6144, 3, device=dev)
 cfg.perturb, cfg.N_samples, cfg.train.lossweights.lpips = 1.0, 128, 0.0
 tr = Trainer(net)
+START = int(os.environ.get('HNRF_START_ITER', 60000))         # steady state: past kick_in_iter / full_band_iter (1 = the cheaper early step)
+tr.iter = START
 def sync(): torch.cuda.synchronize(); return time.perf_counter()
 for it in range(iters):
     t0 = sync(); tr.optimizer.zero_grad(set_to_none=True)
-    out = net(**tb, iter_val=float(it + 1)); t1 = sync()
+    out = net(**tb, iter_val=float(START + it)); t1 = sync()
     loss, _ = image_loss(out['rgb'][None, None], tgt[None, None]); t2 = sync()
     loss.backward(); t3 = sync()
     tr.optimizer.step(); t4 = sync()

@@ -26,6 +26,7 @@ net = Network(); net.load_state_dict({k: torch.from_numpy(v) for k, v in seeded_
 net = net.to(dev)
 for cache in (True, False):
     tr = Trainer(net)
+    tr.iter = int(os.environ.get('HNRF_START_ITER', 60000))   # steady state: past kick_in_iter / full_band_iter (1 = the cheaper early step)
     stream = dataset.FrameStream(subj, device=dev, device_cache=cache, workers=int(os.environ.get("W", 3)), prefetch=int(os.environ.get("PF", 4)))
     cfg.perturb = cfg.train.perturb
     n = iters if cache else max(8, iters // 5)
