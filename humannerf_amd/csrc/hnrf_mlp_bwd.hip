@@ -652,9 +652,13 @@ __global__ __launch_bounds__(NI) void mlp_dwh_head_kernel(const float* __restric
 // thread keeps 4 features x 4 outputs per tile for ITS sample slot, and the 32 slots of a group are summed by wave
 // shuffles once at the end.  Partials in the layout of mlp_dw_head_kernel.
 template <int NI>
-__global__ __launch_bounds__(256) void mlp_dwh_head_blk_kernel(const float* __restrict__ dY, int64_t ldy, int n_out,
-                                                               const _Float16* __restrict__ X, int64_t P, int64_t per_wg,
-                                                               float* __restrict__ part, float* __restrict__ dbpart) {
+__global__ __launch_bounds__(256, 2) void mlp_dwh_head_blk_kernel(const float* __restrict__ dY, int64_t ldy, int n_out,
+                                                                  const _Float16* __restrict__ X, int64_t P, int64_t per_wg,
+                                                                  float* __restrict__ part, float* __restrict__ dbpart) {
+    // Pure streaming: 64 B of X and 16 B of dY per thread and trip.  Round 3: the kernel ran one wave per SIMD (the 128
+    // accumulators + the compiler's free hand up to 512 registers) with the loads of a trip issued and awaited inside it --
+    // 16 KB in flight per CU, 2.4 TB/s.  Now two workgroups per CU (register cap of launch_bounds) and the next trip's
+    // loads issued before this trip's FMAs.
     constexpr int NTILE = NI / 32;
     const int tid = threadIdx.x, k = tid >> 5, slot = tid & 31, c = slot ^ (4 * k);
     const int64_t s0 = (int64_t)blockIdx.x * per_wg;                 // multiple of 32
@@ -667,19 +671,21 @@ __global__ __launch_bounds__(256) void mlp_dwh_head_blk_kernel(const float* __re
 #pragma unroll
             for (int o = 0; o < 4; ++o) acc[t][j][o] = 0.f;
     float bsum[4] = {0.f, 0.f, 0.f, 0.f};
-    for (int64_t sb = s0; sb < s1; sb += 32) {
-        const int64_t s = sb + c;
-        float g[4] = {0.f, 0.f, 0.f, 0.f};
-        if (s < s1) {
+    h16x4 xn[NTILE];
+    float gn[4] = {0.f, 0.f, 0.f, 0.f};
+    // whole 32-sample blocks: unconditional loads (a per-lane `s < s1` around them made the compiler wait for dY inside
+    // the trip); the one ragged block at the end of the last slice is done separately below
+    auto fetch = [&](int64_t sb) {
+        const float* gp = dY + (sb + c) * ldy;
 #pragma unroll
-            for (int o = 0; o < 4; ++o) g[o] = o < n_out ? dY[s * ldy + o] : 0.f;
-        }
+        for (int o = 0; o < 4; ++o) gn[o] = gp[o < n_out ? o : 0];       // (masked where consumed: a select here waits for the load)
+        const _Float16* xb = X + (sb >> 5) * (int64_t)(NI * 32) + tid * 4;
+#pragma unroll
+        for (int t = 0; t < NTILE; ++t) xn[t] = *reinterpret_cast<const h16x4*>(xb + t * 1024);
+    };
+    auto accumulate = [&](const float (&g)[4], const h16x4 (&xv)[NTILE]) {
 #pragma unroll
         for (int o = 0; o < 4; ++o) bsum[o] += g[o];
-        const _Float16* xb = X + (sb >> 5) * (int64_t)(NI * 32) + tid * 4;
-        h16x4 xv[NTILE];
-#pragma unroll
-        for (int t = 0; t < NTILE; ++t) xv[t] = *reinterpret_cast<const h16x4*>(xb + t * 1024);
 #pragma unroll
         for (int t = 0; t < NTILE; ++t)
 #pragma unroll
@@ -688,6 +694,31 @@ __global__ __launch_bounds__(256) void mlp_dwh_head_blk_kernel(const float* __re
 #pragma unroll
                 for (int o = 0; o < 4; ++o) acc[t][j][o] = fmaf(g[o], x, acc[t][j][o]);
             }
+    };
+    const int64_t sfull = s1 > s0 ? s0 + ((s1 - s0) & ~(int64_t)31) : s0;
+    if (s0 < sfull) fetch(s0);
+    for (int64_t sb = s0; sb < sfull; sb += 32) {
+        float g[4];
+        h16x4 xv[NTILE];
+#pragma unroll
+        for (int o = 0; o < 4; ++o) g[o] = o < n_out ? gn[o] : 0.f;
+#pragma unroll
+        for (int t = 0; t < NTILE; ++t) xv[t] = xn[t];
+        if (sb + 32 < sfull) fetch(sb + 32);
+        accumulate(g, xv);
+    }
+    if (sfull < s1) {
+        const int64_t s = sfull + c;
+        float g[4] = {0.f, 0.f, 0.f, 0.f};
+        if (s < s1) {
+#pragma unroll
+            for (int o = 0; o < 4; ++o) g[o] = o < n_out ? dY[s * ldy + o] : 0.f;
+        }
+        h16x4 xv[NTILE];
+        const _Float16* xb = X + (sfull >> 5) * (int64_t)(NI * 32) + tid * 4;
+#pragma unroll
+        for (int t = 0; t < NTILE; ++t) xv[t] = *reinterpret_cast<const h16x4*>(xb + t * 1024);
+        accumulate(g, xv);
     }
     // sum over the 32 sample slots of each feature group (a half wave)
 #pragma unroll
@@ -731,7 +762,10 @@ static bool dwh_plan(int64_t P, int n_out, int n_in, DwPlan& pl) {
     int64_t per = (P + DW_SPLIT - 1) / DW_SPLIT;
     per = (per + 63) / 64 * 64;
     if (per < 128) per = 128;
-    if (pl.now == 4 && per > 512) per = 512;
+    if (pl.now == 4) {                       // head kernels: 512 workgroups = two per CU, all resident at once
+        per = ((P + 511) / 512 + 31) / 32 * 32;
+        if (per < 128) per = 128;
+    }
     pl.per_wg = per;
     pl.nsplit = (int)((P + per - 1) / per);
     return true;

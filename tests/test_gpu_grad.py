@@ -597,11 +597,15 @@ def test_half_operand_weight_gradient_kernel_blocked_layout(P, n_out, n_in):
                                 z_blocked=True, x_blocked=xb)
     assert torch.equal(got_W, want_W) and torch.equal(got_b, want_b)
     if n_in in (128, 256):                 # heads read blocked activations
-        dY = torch.from_numpy(rs.standard_normal((P, 4)).astype(np.float32)).to(dev())
-        a = ops.mlp_dw_h(dY, Xh)
-        b = ops.mlp_dw_h(dY, _to_blocked(Xh), P=P, x_blocked=True)                       # (coalesced form: other summation order)
-        assert float((a[0] - b[0]).abs().max()) <= 2e-6 * float(a[0].abs().max())
-        assert float((a[1] - b[1]).abs().max()) <= 2e-6 * float(a[1].abs().max()) + 1e-4
+        for heads in (4, 3):               # (canonical head: 4 outputs; non-rigid head: 3)
+            dY = torch.from_numpy(rs.standard_normal((P, heads)).astype(np.float32)).to(dev())
+            a = ops.mlp_dw_h(dY, Xh)
+            b = ops.mlp_dw_h(dY, _to_blocked(Xh), P=P, x_blocked=True)                   # (coalesced form: other summation order)
+            assert a[0].shape == (heads, n_in) and b[0].shape == (heads, n_in)
+            assert float((a[0] - b[0]).abs().max()) <= 2e-6 * float(a[0].abs().max())
+            assert float((a[1] - b[1]).abs().max()) <= 2e-6 * float(a[1].abs().max()) + 1e-4
+            ref = dY.double().T @ Xh.double()
+            assert float((b[0].double() - ref).abs().max() / ref.abs().max()) <= 2e-6
 
 
 def test_half_operand_head_gradient_kernel():
