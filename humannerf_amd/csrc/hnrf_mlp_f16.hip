@@ -512,21 +512,30 @@ __device__ __forceinline__ void store_pair_h(_Float16* rowh, int cx, unsigned& s
     }
 }
 
-// sign mask of the f16 forms: acc = 2 acc + [x > 0] (v_cmp + v_addc: 2 VALU per value).  After the 16 values of a tile
-// in register order, value r sits in bit 15 - r; a word takes two tiles, the even one in the upper half.
-__device__ __forceinline__ void push_bit(uint32_t& acc, float x) {
-    asm("v_cmp_lt_f32 vcc, 0, %1\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(acc) : "v"(x) : "vcc");
+// sign mask of the f16 forms, one PAIR of values per push: the pair's hi parts sit packed in one register (the B-operand
+// fragment the next layer consumes), so [h != 0] for both is one v_pk_min_u16 against 1 and acc = 2 acc + bit for both one
+// v_pk_mad_u16 -- 2 VALU per pair where v_cmp + v_addc per value cost 4 (round 3: the masks were 1 072 of the 1 494 VALU
+// instructions the activation-saving forward had over the inference form).  The low half of a word collects the pairs'
+// first values, the high half their second values; a word takes the 16 pairs of two tiles (even tile first), push
+// n = 8 (tile & 1) + pair ends in bit 15 - n of its half.
+// [f16(x) != 0] instead of [x > 0]: the two differ for 0 < x <= 2^-25 only (such a value rounds to a zero hi part), i.e.
+// for pre-activations within 3e-8 of the kink -- two orders of magnitude rarer than the sign flips the forward's own
+// last-bit rounding causes (6e-7 relative), and exact zeros (dead units, all-zero inputs) give 0 as torch does.
+__device__ __forceinline__ void push_pair_bits(uint32_t& acc, h16x2 hh) {
+    const unsigned u = __builtin_bit_cast(unsigned, hh);
+    unsigned tmp;
+    asm("v_pk_min_u16 %1, %2, %3\n\tv_pk_mad_u16 %0, %0, %4, %1" : "+v"(acc), "=&v"(tmp) : "v"(u), "s"(0x00010001u), "s"(0x00020002u));
 }
 
-// Backward epilogue of the f16 form: relu' from that mask (word already shifted so that the tile's bit 15 - r is value
-// r's): a 1-bit signed field extract gives 0 / -1, one AND applies it (2 VALU per value).
-__device__ __forceinline__ h16x2 epi_pair_mh(const f32x16& a1, const f32x16& a2, int i, uint32_t mword, h16x8& hi, h16x8& lo) {
+// Backward epilogue of the f16 form: relu' from that mask (the whole word; n = 8 (tile & 1) + pair as pushed): a 1-bit
+// signed field extract gives 0 / -1, one AND applies it (2 VALU per value).
+__device__ __forceinline__ h16x2 epi_pair_mh(const f32x16& a1, const f32x16& a2, int i, uint32_t mword, int n, h16x8& hi, h16x8& lo) {
     float x0 = fmaf(a2[2 * i], LO_INV, a1[2 * i]);
     float x1 = fmaf(a2[2 * i + 1], LO_INV, a1[2 * i + 1]);
     x0 = __builtin_amdgcn_fmed3f(x0, -65504.f, 65504.f);
     x1 = __builtin_amdgcn_fmed3f(x1, -65504.f, 65504.f);
-    x0 = __uint_as_float(__float_as_uint(x0) & (uint32_t)__builtin_amdgcn_sbfe((int)mword, 15 - 2 * i, 1));
-    x1 = __uint_as_float(__float_as_uint(x1) & (uint32_t)__builtin_amdgcn_sbfe((int)mword, 14 - 2 * i, 1));
+    x0 = __uint_as_float(__float_as_uint(x0) & (uint32_t)__builtin_amdgcn_sbfe((int)mword, 15 - n, 1));
+    x1 = __uint_as_float(__float_as_uint(x1) & (uint32_t)__builtin_amdgcn_sbfe((int)mword, 31 - n, 1));
     const h16x2 hh = __builtin_convertvector(f32x2{x0, x1}, h16x2);
     const float r0 = fmaf((float)hh[0], -LO_SCALE, x0 * LO_SCALE);
     const float r1 = fmaf((float)hh[1], -LO_SCALE, x1 * LO_SCALE);
@@ -690,9 +699,8 @@ __device__ __forceinline__ void layer16(Pipe& p, int nb1, int nb2, h16x8 (&bh)[N
                                 save_pair(*sc, bw, t - 1, i, x0, x1);
                             } else if constexpr (SAVE == SV_ACT_H) {
                                 float x0, x1;
-                                epi_pair_x<RELU, ULO>(pacc1, pacc2, i, oh[2 * (t - 1) + (i >> 2)], ol[2 * (t - 1) + (i >> 2)], x0, x1);
-                                push_bit(bw[(t - 1) >> 1], x0);
-                                push_bit(bw[(t - 1) >> 1], x1);
+                                const h16x2 hh = epi_pair_x<RELU, ULO>(pacc1, pacc2, i, oh[2 * (t - 1) + (i >> 2)], ol[2 * (t - 1) + (i >> 2)], x0, x1);
+                                push_pair_bits(bw[(t - 1) >> 1], hh);
                                 if (i & 1) store_frag_h(rowh, cxh, t - 1, i, oh[2 * (t - 1) + (i >> 2)]);
                             } else if constexpr (SAVE == SV_DZ) {
                                 float x0, x1;
@@ -700,7 +708,7 @@ __device__ __forceinline__ void layer16(Pipe& p, int nb1, int nb2, h16x8 (&bh)[N
                                            oh[2 * (t - 1) + (i >> 2)], ol[2 * (t - 1) + (i >> 2)], x0, x1);
                                 save_pair_b(*sc, t - 1, i, x0, x1);
                             } else if constexpr (SAVE == SV_DZ_H) {
-                                const h16x2 hh = epi_pair_mh(pacc1, pacc2, i, sc->mask[(t - 1) >> 1] >> (16 * (1 - ((t - 1) & 1))),
+                                const h16x2 hh = epi_pair_mh(pacc1, pacc2, i, sc->mask[(t - 1) >> 1], 8 * ((t - 1) & 1) + i,
                                                              oh[2 * (t - 1) + (i >> 2)], ol[2 * (t - 1) + (i >> 2)]);
                                 store_pair_h(rowh, cxh, svu, t - 1, i, hh);
                             } else if constexpr (SAVE == SV_PE) {
@@ -755,9 +763,8 @@ __device__ __forceinline__ void layer16(Pipe& p, int nb1, int nb2, h16x8 (&bh)[N
                 save_pair(*sc, bw, NT - 1, i, x0, x1);
             } else if constexpr (SAVE == SV_ACT_H) {
                 float x0, x1;
-                epi_pair_x<RELU, ULO>(pacc1, pacc2, i, oh[2 * (NT - 1) + (i >> 2)], ol[2 * (NT - 1) + (i >> 2)], x0, x1);
-                push_bit(bw[(NT - 1) >> 1], x0);
-                push_bit(bw[(NT - 1) >> 1], x1);
+                const h16x2 hh = epi_pair_x<RELU, ULO>(pacc1, pacc2, i, oh[2 * (NT - 1) + (i >> 2)], ol[2 * (NT - 1) + (i >> 2)], x0, x1);
+                push_pair_bits(bw[(NT - 1) >> 1], hh);
                 if (i & 1) store_frag_h(rowh, cxh, NT - 1, i, oh[2 * (NT - 1) + (i >> 2)]);
             } else if constexpr (SAVE == SV_DZ) {
                 float x0, x1;
@@ -765,7 +772,7 @@ __device__ __forceinline__ void layer16(Pipe& p, int nb1, int nb2, h16x8 (&bh)[N
                            ol[2 * (NT - 1) + (i >> 2)], x0, x1);
                 save_pair_b(*sc, NT - 1, i, x0, x1);
             } else if constexpr (SAVE == SV_DZ_H) {
-                const h16x2 hh = epi_pair_mh(pacc1, pacc2, i, sc->mask[(NT - 1) >> 1] >> (16 * (1 - ((NT - 1) & 1))),
+                const h16x2 hh = epi_pair_mh(pacc1, pacc2, i, sc->mask[(NT - 1) >> 1], 8 * ((NT - 1) & 1) + i,
                                              oh[2 * (NT - 1) + (i >> 2)], ol[2 * (NT - 1) + (i >> 2)]);
                 store_pair_h(rowh, cxh, svu, NT - 1, i, hh);
             } else if constexpr (SAVE == SV_PE) {
