@@ -229,6 +229,30 @@ __device__ __forceinline__ void dma_piece(const char* gbase, unsigned voff, unsi
         : "memory");
 }
 
+// The same inside the k-loops, where every instruction of the one wave per SIMD costs ~5 cycles of issue next to the
+// MFMAs' 32 (profiles/tools/mfma_issue.hip: 8 + 5 n cycles per MFMA with n other instructions of ANY kind, scalar ones
+// included): the form above is 8 instructions per piece (m0 saved / set / restored, s_nop, two-word source add, LDS
+// address add), 1.3 per MFMA of the canonical kernel.  The instruction's immediate offset applies to BOTH addresses
+// (LDS address = M0 + offset + 16 lane, measured: profiles/tools/dma_offset.hip), so four consecutive 1-KiB pieces
+// share one source base and one M0 value (offsets 0 / 1024 / 2048 / 3072); M0 is handed to the compiler as an operand
+// ("{m0}": it materialises the value and the hazard wait itself, and nothing else in these kernels uses M0).
+// Wave w therefore moves the CONTIGUOUS pieces [w n, (w + 1) n) of a slab (n = pieces per wave), not w, w+4, ...
+template <int R>
+__device__ __forceinline__ void dma_piece_g(const char* gbase, unsigned voff, unsigned lds_addr) {
+    asm volatile("global_load_lds_dwordx4 %0, %1 offset:%3" : : "v"(voff), "s"(gbase), "{m0}"(lds_addr), "n"(R * 1024) : "memory");
+}
+// piece i (compile-time after unrolling) of this wave's run: base addresses of the wave's run in, group of four out
+__device__ __forceinline__ void dma_run_piece(const char* run_src, unsigned voff, unsigned run_dst, int i) {
+    const char* g = run_src + (i >> 2) * 4096;
+    const unsigned d = run_dst + (i >> 2) * 4096;
+    switch (i & 3) {
+        case 0: dma_piece_g<0>(g, voff, d); break;
+        case 1: dma_piece_g<1>(g, voff, d); break;
+        case 2: dma_piece_g<2>(g, voff, d); break;
+        default: dma_piece_g<3>(g, voff, d); break;
+    }
+}
+
 // DMA of nblocks 1-KiB blocks: wave w moves blocks w, w+4, ...  (nblocks % 4 == 0
 // wherever a counted wait follows, so that every wave has the same count in flight)
 __device__ __forceinline__ void slab_issue(const char* gsrc, unsigned lds_addr, int nblocks, int wave) {
@@ -595,9 +619,9 @@ __device__ __forceinline__ void layer16(Pipe& p, int nb1, int nb2, h16x8 (&bh)[N
         // its 1-KiB pieces are issued one per k-step INSIDE this slab's MFMA stream (an LDS-DMA issue
         // costs ~100-150 cycles of the wave's issue slot: 8-10 of them in front of the tile idle the
         // matrix pipe for ~1000 cycles per tile -- measured with cycle stamps)
-        const char* dsrc = p.gi + p.wave * 1024;
-        const unsigned ddst = p.lds_base + p.ring_off + slot2 * p.slab_bytes + p.wave * 1024;
-        const int dcnt = nissue / 4;
+        const int dcnt = nissue / 4;                       // pieces per wave: this wave moves the run [wave dcnt, (wave + 1) dcnt)
+        const char* dsrc = p.gi + p.wave * dcnt * 1024;
+        const unsigned ddst = p.lds_base + p.ring_off + slot2 * p.slab_bytes + p.wave * dcnt * 1024;
         p.gi += nissue * 1024;
 #pragma unroll
         for (int tt = 0; tt < TPS; ++tt) {
@@ -649,12 +673,14 @@ __device__ __forceinline__ void layer16(Pipe& p, int nb1, int nb2, h16x8 (&bh)[N
                     xl = bl[ib];
                 }
                 if (ks + PFK < NK) {
-                    qwh[q] = lds_ld8(cur + (2 * (ks + PFK)) * 1024);
+                    // issue order = reverse of the order of first use (wh and xh by the k-step's first MFMA, xl by its
+                    // second, wl by its third): the compiler's s_waitcnt in front of the first MFMA then covers the
+                    // whole refill and the two further waits per k-step disappear (every instruction of the one wave
+                    // per SIMD costs issue time, s_waitcnt included)
                     qwl[q] = lds_ld8(cur + (2 * (ks + PFK) + 1) * 1024);
-                    if (ks + PFK < NKA) {
-                        qxh[q] = lds_ld8(pe + (2 * (ks + PFK)) * 1024);
-                        qxl[q] = lds_ld8(pe + (2 * (ks + PFK) + 1) * 1024);
-                    }
+                    if (ks + PFK < NKA) qxl[q] = lds_ld8(pe + (2 * (ks + PFK) + 1) * 1024);
+                    qwh[q] = lds_ld8(cur + (2 * (ks + PFK)) * 1024);
+                    if (ks + PFK < NKA) qxh[q] = lds_ld8(pe + (2 * (ks + PFK)) * 1024);
                 }
                 acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, xh, acc1, 0, 0, 0);
                 if (ULO) acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, xl, acc1, 0, 0, 0);
@@ -673,9 +699,9 @@ __device__ __forceinline__ void layer16(Pipe& p, int nb1, int nb2, h16x8 (&bh)[N
                     const int i = tt * NK + ks;
                     if (i >= 0 && i < MAXP) {
                         if (s + 2 < NS) {                      // piece count known at compile time
-                            if (i < NBLK * TPS / 4) dma_piece(dsrc + i * 4096, lane * 16, ddst + i * 4096);
+                            if (i < NBLK * TPS / 4) dma_run_piece(dsrc, lane * 16, ddst, i);
                         } else if (i < dcnt) {                 // wave-uniform branch (layer-boundary slabs)
-                            dma_piece(dsrc + i * 4096, lane * 16, ddst + i * 4096);
+                            dma_run_piece(dsrc, lane * 16, ddst, i);
                         }
                     }
                 }
@@ -809,9 +835,9 @@ __device__ __forceinline__ void layer16x2(Pipe& p, unsigned stash_per_wave, int 
     for (int s = 0; s < NS; ++s) {
         const int nissue = (s + 2 < NS) ? NBLK * TPS : (s + 2 == NS ? nb1 : nb2);
         const unsigned slot2 = p.ph == 0 ? 2 : p.ph - 1;
-        const char* dsrc = p.gi + p.wave * 1024;
-        const unsigned ddst = p.lds_base + p.ring_off + slot2 * p.slab_bytes + p.wave * 1024;
-        const int dcnt = nissue / 4;
+        const int dcnt = nissue / 4;                       // pieces per wave: this wave moves the run [wave dcnt, (wave + 1) dcnt)
+        const char* dsrc = p.gi + p.wave * dcnt * 1024;
+        const unsigned ddst = p.lds_base + p.ring_off + slot2 * p.slab_bytes + p.wave * dcnt * 1024;
         p.gi += nissue * 1024;
 #pragma unroll
         for (int tt = 0; tt < TPS; ++tt) {
@@ -859,14 +885,16 @@ __device__ __forceinline__ void layer16x2(Pipe& p, unsigned stash_per_wave, int 
                     }
                 }
                 if (ks + PFK < NK) {
-                    qwh[q] = lds_ld8(cur + (2 * (ks + PFK)) * 1024);
+                    // (issue order = reverse of the order of first use, see layer16)
                     qwl[q] = lds_ld8(cur + (2 * (ks + PFK) + 1) * 1024);
                     if (ks + PFK < NKA) {
 #pragma unroll
-                        for (int g = 0; g < 2; ++g) {
-                            qxh[g][q] = lds_ld8(pe + g * (stash_per_wave / 2) + (2 * (ks + PFK)) * 1024);
-                            qxl[g][q] = lds_ld8(pe + g * (stash_per_wave / 2) + (2 * (ks + PFK) + 1) * 1024);
-                        }
+                        for (int g = 1; g >= 0; --g) qxl[g][q] = lds_ld8(pe + g * (stash_per_wave / 2) + (2 * (ks + PFK) + 1) * 1024);
+                    }
+                    qwh[q] = lds_ld8(cur + (2 * (ks + PFK)) * 1024);
+                    if (ks + PFK < NKA) {
+#pragma unroll
+                        for (int g = 1; g >= 0; --g) qxh[g][q] = lds_ld8(pe + g * (stash_per_wave / 2) + (2 * (ks + PFK)) * 1024);
                     }
                 }
 #pragma unroll
@@ -881,9 +909,9 @@ __device__ __forceinline__ void layer16x2(Pipe& p, unsigned stash_per_wave, int 
                     const int i = tt * NK + ks;
                     if (i >= 0 && i < MAXP) {
                         if (s + 2 < NS) {
-                            if (i < NBLK * TPS / 4) dma_piece(dsrc + i * 4096, lane * 16, ddst + i * 4096);
+                            if (i < NBLK * TPS / 4) dma_run_piece(dsrc, lane * 16, ddst, i);
                         } else if (i < dcnt) {
-                            dma_piece(dsrc + i * 4096, lane * 16, ddst + i * 4096);
+                            dma_run_piece(dsrc, lane * 16, ddst, i);
                         }
                     }
                 }

@@ -24,3 +24,6 @@ k, b = dbg[:, 0].astype(np.float64), dbg[:, 1].astype(np.float64)
 print('k-loop cycles per WG-wave: median %.0f  (ideal 2928*32 = 93696)' % np.median(k))
 print('outside k-loops:           median %.0f' % np.median(b))
 print('per slab step (59): k %.0f, other %.0f' % (np.median(k) / 59, np.median(b) / 59))
+if dbg[:, 2].any():
+    print('of the other: DMA wait (s_waitcnt vmcnt) median %.0f, barrier median %.0f (per step %.0f / %.0f)' % (
+        np.median(dbg[:, 2]), np.median(dbg[:, 3]), np.median(dbg[:, 2]) / 59, np.median(dbg[:, 3]) / 59))
