@@ -36,8 +36,14 @@ __global__ __launch_bounds__(256) void sample_warp_kernel(
     int64_t P, int S, int B, int G,
     float* __restrict__ z_vals, float* __restrict__ x_skel,
     float* __restrict__ fg_mask, float* __restrict__ bmw) {
-    const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (p >= P) return;
+    // the diagnostic per-bone weights of a block's 256 samples are one contiguous run of 256 B floats: staged in LDS as
+    // [quad of bones][sample] and written back as whole 1-KiB wavefront stores (as they leave the bone loop -- 16 bytes
+    // per lane at a 96-byte stride -- every store instruction touched 64 different 128-byte lines: 1.28 GB of write
+    // requests per chunk for 0.40 GB of weights, profiles/r03_frame_traffic.csv)
+    __shared__ float4 stage[WRITE_BMW ? 6 * 256 : 1];
+    const int64_t p_raw = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const bool in_range = p_raw < P;
+    const int64_t p = in_range ? p_raw : P - 1;        // (lanes past the end recompute the last sample and store nothing)
     const int64_t r = p / S;
     const int s = (int)(p - r * S);
 
@@ -62,7 +68,7 @@ __global__ __launch_bounds__(256) void sample_warp_kernel(
     float wsum = 0.f, ax = 0.f, ay = 0.f, az = 0.f;
     // four bones per trip (their 16 gathers in flight together); the diagnostic per-bone weights leave as one 16-byte
     // store per trip instead of four 4-byte stores at a 96-byte stride between lanes
-    const bool bmw4 = WRITE_BMW && (B & 3) == 0;
+    const bool bmw4 = WRITE_BMW && B == 24;            // staged form (the default skeleton); any other B: plain stores
     for (int b0 = 0; b0 < B; b0 += 4) {
     float w4[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -117,16 +123,29 @@ __global__ __launch_bounds__(256) void sample_warp_kernel(
         ay += w * qy;
         az += w * qz;
         w4[j] = w;
-        if (WRITE_BMW && !bmw4) bmw[p * B + b] = w;
+        if (WRITE_BMW && !bmw4 && in_range) bmw[p * B + b] = w;
     }
-    if (bmw4) *reinterpret_cast<float4*>(bmw + p * B + b0) = make_float4(w4[0], w4[1], w4[2], w4[3]);
+    if (bmw4) stage[(b0 >> 2) * 256 + threadIdx.x] = make_float4(w4[0], w4[1], w4[2], w4[3]);
     }
-    const float den = fmaxf(wsum, 0.0001f);
-    z_vals[p] = z;
-    x_skel[p * 3 + 0] = ax / den;
-    x_skel[p * 3 + 1] = ay / den;
-    x_skel[p * 3 + 2] = az / den;
-    fg_mask[p] = wsum;
+    if (in_range) {
+        const float den = fmaxf(wsum, 0.0001f);
+        z_vals[p] = z;
+        x_skel[p * 3 + 0] = ax / den;
+        x_skel[p * 3 + 1] = ay / den;
+        x_skel[p * 3 + 2] = az / den;
+        fg_mask[p] = wsum;
+    }
+    if (bmw4) {                                        // (block-uniform: no thread has left the kernel)
+        __syncthreads();
+        const int64_t base = (int64_t)blockIdx.x * 256;
+        const int nq = (int)((P - base < 256 ? P - base : 256) * 6);       // float4s of this block's run
+        float4* out = reinterpret_cast<float4*>(bmw + base * 24);
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+            const int o = k * 256 + threadIdx.x;       // linear float4 of the run = sample o / 6, quad o % 6
+            if (o < nq) out[o] = stage[(o % 6) * 256 + o / 6];
+        }
+    }
 }
 
 // Stream compaction of the samples worth evaluating: idx[0..count) = indices p with fg_mask[p] >= eps.
@@ -180,6 +199,8 @@ extern "C" int hnrf_sample_warp_fwd(const float* rays_o, const float* rays_d,
     HNRF_REQUIRE(z_vals && x_skel && fg_mask, HNRF_E_ARG, "hnrf_sample_warp_fwd: null output pointer");
     HNRF_REQUIRE(R >= 0 && S >= 2 && B >= 1 && G >= 2 && G <= 1024, HNRF_E_ARG,
                  "hnrf_sample_warp_fwd: bad dims R=%lld S=%d B=%d G=%d", (long long)R, S, B, G);
+    HNRF_REQUIRE(!bmw || ((uintptr_t)bmw & 15) == 0, HNRF_E_ARG,
+                 "hnrf_sample_warp_fwd: the per-bone weight output must be 16-byte aligned (it is written in 16-byte pieces)");
     if (R == 0) return HNRF_OK;
     const int64_t P = R * (int64_t)S;
     const int64_t blocks = (P + 255) / 256;

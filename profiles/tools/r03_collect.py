@@ -77,3 +77,39 @@ with open(os.path.join(P, 'r03_train_traffic.csv'), 'w') as fo:
 for r in rows[:24]:
     print(r)
 print('total ms %.2f  read %.0f MB  write %.0f MB' % (tot_ms, tot_rd, tot_wr))
+
+
+# rendering frame: per kernel average launch time, HBM bytes per launch, MFMA busy / clock (separate PMC passes of the same command)
+import subprocess, sys
+sq_json = os.path.join(P, 'r03_pmc_sq_f16x3_summary.json')
+subprocess.run([sys.executable, os.path.join(P, 'tools', 'pmc_sq.py'), one('r03_pmc_sq/*/*_counter_collection.csv'), '-', sq_json,
+                'canonical_f16x3', 'nonrigid_f16x3', 'sample_warp', 'composite'], check=True, stdout=subprocess.DEVNULL)
+tsq = glob.glob(os.path.join(G, 'r03_pmc_tsq/*/*_counter_collection.csv'))
+if tsq:
+    subprocess.run([sys.executable, os.path.join(P, 'tools', 'pmc_sq.py'), one('r03_pmc_tsq/*/*_counter_collection.csv'), '-',
+                    os.path.join(P, 'r03_pmc_sq_train_summary.json'), 'canonical', 'nonrigid', 'mlp_dwh', 'sample_warp'],
+                   check=True, stdout=subprocess.DEVNULL)
+sq = json.load(open(sq_json))
+f = pmc('r03_pmc_fetch/*/*_counter_collection.csv', 'FETCH_SIZE')
+w = pmc('r03_pmc_write/*/*_counter_collection.csv', 'WRITE_SIZE')
+fstats = {r['Name']: r for r in csv.DictReader(open(one('r03_main/*/*_kernel_stats.csv')))}
+frows = []
+for name, r in fstats.items():
+    if not any(k in name for k in ('canonical_f16x3', 'nonrigid_f16x3', 'sample_warp', 'composite_kernel')):
+        continue
+    fr = sum(f.get(name, [0.])) / max(len(f.get(name, [0.])), 1) * 2 * 1024
+    wr = sum(w.get(name, [0.])) / max(len(w.get(name, [0.])), 1) * 1024
+    key = name.split('(')[0].replace('void ', '')
+    rec = sq.get(key, {})
+    ms = float(r['AverageNs']) / 1e6
+    frows.append({'kernel': short(name), 'launches': r['Calls'], 'avg_ms': round(ms, 4), 'hbm_read_MB': round(fr / 1e6, 1),
+                  'hbm_write_MB': round(wr / 1e6, 1), 'TB_per_s': round((fr + wr) / (ms * 1e-3) / 1e12, 3),
+                  'mfma_busy': round(rec.get('mfma_busy_frac', 0.0), 3), 'clock_GHz': round(rec.get('clock_GHz') or 0.0, 2)})
+frows.sort(key=lambda r: -r['avg_ms'])
+with open(os.path.join(P, 'r03_frame_traffic.csv'), 'w') as fo:
+    wtr = csv.DictWriter(fo, fieldnames=list(frows[0]))
+    wtr.writeheader()
+    for r in frows:
+        wtr.writerow(r)
+for r in frows:
+    print(r)
