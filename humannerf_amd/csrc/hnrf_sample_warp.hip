@@ -20,12 +20,15 @@ struct __attribute__((packed, aligned(4))) f32x2u { float x, y; };
 // torch.linspace(0, 1, S)[s] in fp32 (start + step*i below the midpoint,
 // end - step*(S-1-i) above it), then the reference's lerp (network.py:457-458).
 __device__ __forceinline__ float z_at(float nr, float fr, int s, int S) {
+#pragma clang fp contract(off)
     const float step = 1.0f / (float)(S - 1);
     const float t = (s < S / 2) ? step * (float)s : 1.0f - step * (float)(S - 1 - s);
     return nr * (1.0f - t) + fr * t;
 }
 
-template <bool WRITE_BMW>
+// BT: the bone count as a compile-time constant (24 = the SMPL skeleton of every config of the reference; 0 = read B at
+// run time).  With BT the four-bone trips lose their per-bone `b < B` branches.
+template <bool WRITE_BMW, int BT>
 __global__ __launch_bounds__(256) void sample_warp_kernel(
     const float* __restrict__ rays_o, const float* __restrict__ rays_d,
     const float* __restrict__ near, const float* __restrict__ far,
@@ -40,6 +43,11 @@ __global__ __launch_bounds__(256) void sample_warp_kernel(
     // [quad of bones][sample] and written back as whole 1-KiB wavefront stores (as they leave the bone loop -- 16 bytes
     // per lane at a 96-byte stride -- every store instruction touched 64 different 128-byte lines: 1.28 GB of write
     // requests per chunk for 0.40 GB of weights, profiles/r03_frame_traffic.csv)
+    // Arithmetic: every operation of the reference's tensor expressions is rounded on its own (no compiler-chosen fma:
+    // with contraction left to hipcc, two instances of this template could differ in the last bit of a grid coordinate,
+    // which the division by a small weight sum turns into 1e-4 of x_skel); the one place that IS a sum of products in
+    // the reference (the 3x3 transform: a matmul) use explicit fmaf.
+#pragma clang fp contract(off)
     __shared__ float4 stage[WRITE_BMW ? 6 * 256 : 1];
     const int64_t p_raw = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const bool in_range = p_raw < P;
@@ -68,18 +76,19 @@ __global__ __launch_bounds__(256) void sample_warp_kernel(
     float wsum = 0.f, ax = 0.f, ay = 0.f, az = 0.f;
     // four bones per trip (their 16 gathers in flight together); the diagnostic per-bone weights leave as one 16-byte
     // store per trip instead of four 4-byte stores at a 96-byte stride between lanes
-    const bool bmw4 = WRITE_BMW && B == 24;            // staged form (the default skeleton); any other B: plain stores
-    for (int b0 = 0; b0 < B; b0 += 4) {
+    const bool bmw4 = WRITE_BMW && BT == 24;           // staged form (the default skeleton); any other B: plain stores
+    const int Bn = BT ? BT : B;
+    for (int b0 = 0; b0 < Bn; b0 += 4) {
     float w4[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int b = b0 + j;
-        if (b >= B) break;
+        if (!BT && b >= B) break;
         const float* Rb = Rs + b * 9;   // wave-uniform address: scalar loads
         const float* Tb = Ts + b * 3;
-        const float qx = Rb[0] * px + Rb[1] * py + Rb[2] * pz + Tb[0];
-        const float qy = Rb[3] * px + Rb[4] * py + Rb[5] * pz + Tb[1];
-        const float qz = Rb[6] * px + Rb[7] * py + Rb[8] * pz + Tb[2];
+        const float qx = fmaf(Rb[2], pz, fmaf(Rb[1], py, Rb[0] * px)) + Tb[0];
+        const float qy = fmaf(Rb[5], pz, fmaf(Rb[4], py, Rb[3] * px)) + Tb[1];
+        const float qz = fmaf(Rb[8], pz, fmaf(Rb[7], py, Rb[6] * px)) + Tb[2];
         // normalised grid coordinate, then grid_sample's align_corners un-normalise
         const float ix = (((qx - bmx) * bsx - 1.0f) + 1.0f) * 0.5f * gm1;
         const float iy = (((qy - bmy) * bsy - 1.0f) + 1.0f) * 0.5f * gm1;
@@ -100,26 +109,36 @@ __global__ __launch_bounds__(256) void sample_warp_kernel(
         const bool lo_is_a = (x0 == xb), hi_is_b = (x0 == xb);   // x0 == G-1 -> corner 0 is .y; x0 == -1 -> corner 1 is .x
         const int cy0 = min(max(y0, 0), G - 1), cy1 = min(max(y0 + 1, 0), G - 1);
         const int cz0 = min(max(z0, 0), G - 1), cz1 = min(max(z0 + 1, 0), G - 1);
-        const float* vb = vol + (size_t)b * G * GG + xb;
-        const f32x2u p00 = *(const f32x2u*)(vb + cz0 * GG + cy0 * G);
-        const f32x2u p01 = *(const f32x2u*)(vb + cz0 * GG + cy1 * G);
-        const f32x2u p10 = *(const f32x2u*)(vb + cz1 * GG + cy0 * G);
-        const f32x2u p11 = *(const f32x2u*)(vb + cz1 * GG + cy1 * G);
+        // wave-uniform base (SGPR pair) + one unsigned element offset per gather: with the lane's x folded into the
+        // pointer every gather paid a sign extension and a 64-bit add chain of its own (this kernel is VALU-bound)
+        const float* vb = vol + (size_t)b * G * GG;
+        const unsigned rz0 = (unsigned)(cz0 * GG + xb), rz1 = (unsigned)(cz1 * GG + xb);
+        const unsigned ry0 = (unsigned)(cy0 * G), ry1 = (unsigned)(cy1 * G);
+        const f32x2u p00 = *(const f32x2u*)(vb + (rz0 + ry0));
+        const f32x2u p01 = *(const f32x2u*)(vb + (rz0 + ry1));
+        const f32x2u p10 = *(const f32x2u*)(vb + (rz1 + ry0));
+        const f32x2u p11 = *(const f32x2u*)(vb + (rz1 + ry1));
         const float v000 = lo_is_a ? p00.x : p00.y, v001 = hi_is_b ? p00.y : p00.x;
         const float v010 = lo_is_a ? p01.x : p01.y, v011 = hi_is_b ? p01.y : p01.x;
         const float v100 = lo_is_a ? p10.x : p10.y, v101 = hi_is_b ? p10.y : p10.x;
         const float v110 = lo_is_a ? p11.x : p11.y, v111 = hi_is_b ? p11.y : p11.x;
+        // zero padding through the six 1-D weights instead of eight per-corner selects: an out-of-range corner gets the
+        // product value * (0 * . * .) = 0, and adding that zero leaves the sum's bits as skipping the corner did (the
+        // value gathered at the clamped address is a finite entry of the volume); in-range corners: the same products
+        const float ux0 = vx0 ? wx0 : 0.f, ux1 = vx1 ? wx1 : 0.f;
+        const float uy0 = vy0 ? wy0 : 0.f, uy1 = vy1 ? wy1 : 0.f;
+        const float uz0 = vz0 ? wz0 : 0.f, uz1 = vz1 ? wz1 : 0.f;
         float w = 0.f;
-        w += (vz0 & vy0 & vx0) ? v000 * (wx0 * wy0 * wz0) : 0.f;
-        w += (vz0 & vy0 & vx1) ? v001 * (wx1 * wy0 * wz0) : 0.f;
-        w += (vz0 & vy1 & vx0) ? v010 * (wx0 * wy1 * wz0) : 0.f;
-        w += (vz0 & vy1 & vx1) ? v011 * (wx1 * wy1 * wz0) : 0.f;
-        w += (vz1 & vy0 & vx0) ? v100 * (wx0 * wy0 * wz1) : 0.f;
-        w += (vz1 & vy0 & vx1) ? v101 * (wx1 * wy0 * wz1) : 0.f;
-        w += (vz1 & vy1 & vx0) ? v110 * (wx0 * wy1 * wz1) : 0.f;
-        w += (vz1 & vy1 & vx1) ? v111 * (wx1 * wy1 * wz1) : 0.f;
+        w += v000 * (ux0 * uy0 * uz0);
+        w += v001 * (ux1 * uy0 * uz0);
+        w += v010 * (ux0 * uy1 * uz0);
+        w += v011 * (ux1 * uy1 * uz0);
+        w += v100 * (ux0 * uy0 * uz1);
+        w += v101 * (ux1 * uy0 * uz1);
+        w += v110 * (ux0 * uy1 * uz1);
+        w += v111 * (ux1 * uy1 * uz1);
         wsum += w;
-        ax += w * qx;
+        ax += w * qx;                   // (product rounded, then summed: torch.sum over the stacked w_b * pos_b, network.py:437-441)
         ay += w * qy;
         az += w * qz;
         w4[j] = w;
@@ -206,13 +225,11 @@ extern "C" int hnrf_sample_warp_fwd(const float* rays_o, const float* rays_d,
     const int64_t blocks = (P + 255) / 256;
     HNRF_REQUIRE(blocks < (int64_t)2147483647, HNRF_E_ARG, "hnrf_sample_warp_fwd: too many samples");
     hipStream_t st = (hipStream_t)stream;
-    if (bmw)
-        hipLaunchKernelGGL(sample_warp_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, st, rays_o, rays_d, near,
-                           far, t_rand, motion_Rs, motion_Ts, vol, bbox_min, bbox_scale, P, S, B, G, z_vals, x_skel,
-                           fg_mask, bmw);
-    else
-        hipLaunchKernelGGL(sample_warp_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, st, rays_o, rays_d, near,
-                           far, t_rand, motion_Rs, motion_Ts, vol, bbox_min, bbox_scale, P, S, B, G, z_vals, x_skel,
-                           fg_mask, bmw);
+#define HNRF_K1(W, BT_)                                                                                               \
+    hipLaunchKernelGGL((sample_warp_kernel<W, BT_>), dim3((unsigned)blocks), dim3(256), 0, st, rays_o, rays_d, near, far, \
+                       t_rand, motion_Rs, motion_Ts, vol, bbox_min, bbox_scale, P, S, B, G, z_vals, x_skel, fg_mask, bmw)
+    if (bmw) { if (B == 24) HNRF_K1(true, 24); else HNRF_K1(true, 0); }
+    else { if (B == 24) HNRF_K1(false, 24); else HNRF_K1(false, 0); }
+#undef HNRF_K1
     return check_launch("hnrf_sample_warp_fwd");
 }
