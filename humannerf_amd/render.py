@@ -302,7 +302,7 @@ class FramePrefetcher:
     and hands over device tensors plus the event that marks them ready.  The render stream only ever waits for that
     event: no host synchronisation is left in the loop, so the GPU renders frame n while the host prepares n+1.."""
 
-    def __init__(self, frames, indices, device, show_truth=False, depth=4, workers=3):
+    def __init__(self, frames, indices, device, show_truth=False, depth=4, workers=3, max_workers=6):
         self.frames, self.indices, self.device, self.show_truth = frames, list(indices), device, show_truth
         self.on_gpu = device.type == 'cuda'
         self._resident = {}
@@ -316,6 +316,12 @@ class FramePrefetcher:
             # read-backs on a side stream, and once the renderer runs ahead (nothing in the loop waits for the GPU) each
             # of them queues behind a canonical-MLP launch that holds every SIMD for ~9 ms: 150-200 ms of latency per
             # frame, hidden by building three frames at a time (measured: profiles/r03_movement_loop.txt)
+            # ... and more when that is not enough: the latency depends on the box (host speed, how the two hardware
+            # queues interleave), and a faster renderer needs more frames in the making -- round 3: 3 builders fell from
+            # 1.04x to 1.22x of the pure render time on one box when the render went from 97 to 87 ms, while 5 builders
+            # from the start stalled single frames on another.  So the pool GROWS by one builder (and one slot of depth)
+            # whenever the renderer had to wait for two frames in a row, up to max_workers.
+            self._max_workers, self._waited_in_a_row = max(workers, max_workers), 0
             self._threads = [threading.Thread(target=self._work, daemon=True) for _ in range(max(1, workers))]
             for t in self._threads:
                 t.start()
@@ -413,6 +419,14 @@ class FramePrefetcher:
                 item = self._done.pop(ticket)
             self.wait_s.append(time.perf_counter() - t0)
             self._slots.release()
+            # (the first frames always wait: the pipeline is filling)
+            self._waited_in_a_row = self._waited_in_a_row + 1 if (self.wait_s[-1] > 5e-3 and ticket >= len(self._threads)) else 0
+            if self._waited_in_a_row >= 2 and len(self._threads) < self._max_workers:
+                self._waited_in_a_row = 0
+                t = threading.Thread(target=self._work, daemon=True)
+                self._threads.append(t)
+                self._slots.release()                                    # one more frame in the making
+                t.start()
             main.wait_event(item['event'])
             for t in list(item['data'].values()) + [item['ray_index'], item['truth']]:
                 if torch.is_tensor(t):
@@ -427,7 +441,7 @@ class FramePrefetcher:
                 self._slots.release()
 
 
-def render_frames(network, frames, rank=0, world=1, device=None, on_image=None, show_truth=False, prefetch=4):
+def render_frames(network, frames, rank=0, world=1, device=None, on_image=None, show_truth=False, prefetch=None):
     """Render ``frames`` (sequence of per-frame input dicts, numpy or tensors) frame-sharded.
 
     Returns {frame_idx: uint8 rgb image on the host} for this rank's frames.  ``on_image(idx, rgb8, alpha8[,
@@ -526,7 +540,12 @@ def render_frames(network, frames, rank=0, world=1, device=None, on_image=None, 
     def known(entry):
         return not guard or network.f16_range_checked >= entry[4]
 
-    pre = FramePrefetcher(frames, hdist.frame_shard(len(frames), rank, world), device, show_truth=show_truth, depth=prefetch)
+    # frames in the making at once: a frame's build takes ~260 ms of LATENCY behind the render kernels, the render 85 ms;
+    # three builders to start with, FramePrefetcher adds more while the renderer has to wait (14 MB of device memory per frame)
+    workers = int(os.environ.get('HNRF_PREFETCH_WORKERS', 3))
+    depth = int(prefetch) if prefetch is not None else workers + 1
+    pre = FramePrefetcher(frames, hdist.frame_shard(len(frames), rank, world), device, show_truth=show_truth, depth=depth,
+                          workers=workers)
     try:
         for item in pre:
             hits = network.f16_range_hits if guard else 0
@@ -548,7 +567,7 @@ def render_frames(network, frames, rank=0, world=1, device=None, on_image=None, 
         pre.close()
         cfg.perturb = old
         ms = lambda ts: [round(t * 1e3, 2) for t in ts]
-        render_frames.last_prefetch = {'build_ms': ms(pre.build_s), 'wait_ms': ms(pre.wait_s), 'submit_ms': ms(t_submit),
+        render_frames.last_prefetch = {'workers': len(getattr(pre, '_threads', [])), 'build_ms': ms(pre.build_s), 'wait_ms': ms(pre.wait_s), 'submit_ms': ms(t_submit),
                                        'image_wait_ms': ms(t_wait), 'on_image_ms': ms(t_user)}
         if gpu_ev:
             torch.cuda.synchronize(device)

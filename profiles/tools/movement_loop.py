@@ -56,7 +56,7 @@ print('%s: %d frames, %.0f rays per frame; pure render %.2f ms per frame; run_mo
          pure * 1e3, loop * 1e3, 1 / loop, loop / pure, first * 1e3, steady * 1e3, steady / pure), flush=True)
 print('psnr', res['metrics'])
 lp = render.render_frames.last_prefetch
-print('prefetch: build ms median %.1f max %.1f; renderer waited ms median %.2f max %.1f' % (np.median(lp['build_ms']), max(lp['build_ms']), np.median(lp['wait_ms']), max(lp['wait_ms'])))
+print('prefetch: %d builders at the end; build ms median %.1f max %.1f; renderer waited ms median %.2f max %.1f' % (lp.get('workers', 0), np.median(lp['build_ms']), max(lp['build_ms']), np.median(lp['wait_ms']), max(lp['wait_ms'])))
 print('main thread per frame (median ms): submit %.2f, wait for image %.2f, on_image %.2f' % tuple(np.median(lp[k]) for k in ('submit_ms', 'image_wait_ms', 'on_image_ms')))
 
 if 'gpu_ms' in lp:
