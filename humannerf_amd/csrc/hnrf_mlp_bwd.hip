@@ -608,6 +608,138 @@ __global__ __launch_bounds__(256) void mlp_dwh_kernel(const _Float16* __restrict
     }
 }
 
+// The same for BOTH operands in the blocked layout (the hidden layers of the training step: 12 of its 18 weight-gradient
+// launches), fed by LDS-DMA instead of through registers.  A stage of the blocked layout is one contiguous run that is
+// copied to LDS as it stands -- exactly what `global_load_lds_dwordx4` does -- so the staging registers (64 VGPRs), the
+// ds_write instructions and their waits go, and with them the limit of two stages in flight: four LDS buffers (128 KiB
+// for the 256 x 256 layers), three stages under way while the fourth is multiplied.  Each wave copies a contiguous 4-KiB
+// (2-KiB) run of the dZ part and one of the X part per stage: one source base and one M0 per run, the pieces through the
+// instruction's immediate offset (which applies to both addresses, profiles/tools/dma_offset.hip).  Stage order, and with it
+// the summation order, is that of mlp_dwh_kernel: the results are bit-identical.
+template <int R>
+__device__ __forceinline__ void dwh_dma_piece(const char* gbase, unsigned voff, unsigned lds_addr) {
+    asm volatile("global_load_lds_dwordx4 %0, %1 offset:%3" : : "v"(voff), "s"(gbase), "{m0}"(lds_addr), "n"(R * 1024) : "memory");
+}
+template <int NP>
+__device__ __forceinline__ void dwh_dma_run(const char* gbase, unsigned voff, unsigned lds_addr) {
+    static_assert(NP == 2 || NP == 4, "pieces per wave and operand");
+    dwh_dma_piece<0>(gbase, voff, lds_addr);
+    dwh_dma_piece<1>(gbase, voff, lds_addr);
+    if (NP == 4) {
+        dwh_dma_piece<2>(gbase, voff, lds_addr);
+        dwh_dma_piece<3>(gbase, voff, lds_addr);
+    }
+}
+__device__ __forceinline__ void dwh_wait_keep(int keep) {               // at most `keep` DMA pieces of this wave still in flight
+#define HNRF_VM(N) case N: asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory"); break;
+    switch (keep) {
+        HNRF_VM(4) HNRF_VM(8) HNRF_VM(12) HNRF_VM(16) HNRF_VM(20) HNRF_VM(24) HNRF_VM(28) HNRF_VM(32)
+        default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    }
+#undef HNRF_VM
+}
+
+// LDS buffers = stages under way + 1.  Four: five (256 x 256: all 160 KiB) / eight (128 x 128) measured no faster --
+// 5.6-5.7 TB/s of operand reads + partial-sum writes is what this access pattern gets from the HBM (guide: 6.0-6.3 for a
+// pure stream)
+constexpr int dwh_dma_bufs(int stage_bytes) { return 160 * 1024 / stage_bytes < 4 ? 160 * 1024 / stage_bytes : 4; }
+
+template <int OT, int IT>
+__global__ __launch_bounds__(256) void mlp_dwh_dma_kernel(const _Float16* __restrict__ dZ, const _Float16* __restrict__ X,
+                                                          int64_t P, int64_t per_wg, const float* __restrict__ dz_scale,
+                                                          float* __restrict__ part, float* __restrict__ dbpart) {
+    constexpr int NOW = 128 * OT, NIP = 32 * IT;
+    constexpr int ZB = 32 * NOW * 2, XB = 32 * NIP * 2, SB = ZB + XB;   // bytes per stage (32 samples)
+    constexpr int ZP = ZB / 4096, XP = XB / 4096, PW = ZP + XP;         // 1-KiB pieces per wave and stage
+    constexpr int NBUF = dwh_dma_bufs(SB), AHEAD = NBUF - 1;            // stages under way beside the one being multiplied
+    static_assert(NIP >= 128, "blocked X: hidden layers only");
+    static_assert((AHEAD - 1) * PW <= 63, "vmcnt is a 6-bit counter");
+    extern __shared__ __attribute__((aligned(16))) char dwh_lds[];
+    const unsigned lbase = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) char*)dwh_lds);
+    const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int64_t s0 = (int64_t)blockIdx.x * per_wg;                    // multiple of 32: a block start
+    const int64_t s1 = s0 + per_wg < P ? s0 + per_wg : P;
+    const int64_t ns = (s1 - s0 + 31) / 32;                             // stages of this slice (the last block may be ragged:
+                                                                        // rows past P are zero in a blocked dZ)
+    f32x16 acc[OT][IT];
+#pragma unroll
+    for (int a = 0; a < OT; ++a)
+#pragma unroll
+        for (int b = 0; b < IT; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+    float bsum[OT];
+#pragma unroll
+    for (int a = 0; a < OT; ++a) bsum[a] = 0.f;
+
+    const int g = lane >> 4, pq = lane & 15, q = pq >> 2, pp = pq & 3;
+    int bpos[2][2];
+    {
+        const int k = pp + 4 * (g & 1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) bpos[ks][j] = (k * 32 + ((8 * (g >> 1) + q + 16 * ks + 4 * j) ^ (4 * k))) * 8;
+    }
+    const unsigned voff = lane * 16;
+    auto issue = [&](int64_t stage) {                                   // wave-uniform
+        const int64_t blk = (s0 >> 5) + stage;
+        const unsigned dst = lbase + (unsigned)(stage % NBUF) * SB;
+        dwh_dma_run<ZP>(reinterpret_cast<const char*>(dZ + blk * (int64_t)(NOW * 32)) + w * (ZP * 1024), voff, dst + w * (ZP * 1024));
+        dwh_dma_run<XP>(reinterpret_cast<const char*>(X + blk * (int64_t)(NIP * 32)) + w * (XP * 1024), voff, dst + ZB + w * (XP * 1024));
+    };
+    auto compute = [&](int buf) {
+        const unsigned lb = lbase + buf * SB;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            h16x8 af[OT];
+#pragma unroll
+            for (int a = 0; a < OT; ++a) {
+                af[a] = dwh_frag2(lb + (OT * w + a) * 2048 + bpos[ks][0], lb + (OT * w + a) * 2048 + bpos[ks][1]);
+#pragma unroll
+                for (int j = 0; j < 8; j += 2)
+                    bsum[a] = __builtin_amdgcn_fdot2(h16x2{af[a][j], af[a][j + 1]}, h16x2{(_Float16)1.0f, (_Float16)1.0f}, bsum[a], false);
+            }
+#pragma unroll
+            for (int it = 0; it < IT; ++it) {
+                const h16x8 bf = dwh_frag2(lb + ZB + it * 2048 + bpos[ks][0], lb + ZB + it * 2048 + bpos[ks][1]);
+#pragma unroll
+                for (int a = 0; a < OT; ++a) acc[a][it] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[a], bf, acc[a][it], 0, 0, 0);
+            }
+        }
+    };
+
+#pragma unroll
+    for (int d = 0; d < AHEAD; ++d)
+        if (d < ns) issue(d);
+    for (int64_t s = 0; s < ns; ++s) {
+        const int64_t younger = ns - 1 - s < AHEAD - 1 ? ns - 1 - s : AHEAD - 1;   // stages issued after stage s
+        dwh_wait_keep((int)younger * PW);                               // this wave's pieces of stage s have landed ...
+        __syncthreads();                                                // ... and everybody's; everybody is done with stage s - 1
+        if (s + AHEAD < ns) issue(s + AHEAD);                           // into the buffer of stage s - 1
+        compute((int)(s % NBUF));
+    }
+
+    const float inv = dz_scale ? 1.0f / dz_scale[0] : 1.0f;
+    const int c = lane & 31, h = lane >> 5;
+    float* out = part + (int64_t)blockIdx.x * NOW * NIP;
+#pragma unroll
+    for (int a = 0; a < OT; ++a)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int o = 32 * OT * w + 32 * a + (r & 3) + 8 * (r >> 2) + 4 * h;
+#pragma unroll
+            for (int it = 0; it < IT; ++it) out[(int64_t)o * NIP + 32 * it + c] = acc[a][it][r] * inv;
+        }
+    if (dbpart != nullptr) {
+#pragma unroll
+        for (int a = 0; a < OT; ++a) {
+            const float t = bsum[a] + __shfl_xor(bsum[a], 32, 64);
+            if (h == 0) dbpart[(int64_t)blockIdx.x * NOW + 32 * OT * w + 32 * a + c] = t * inv;
+        }
+    }
+}
+
 // head layers with f16 activations: mlp_dw_head_kernel reading X as halves (XBLK: blocked layout, see mlp_dwh_kernel)
 template <int NI, bool XBLK>
 __global__ __launch_bounds__(NI) void mlp_dwh_head_kernel(const float* __restrict__ dY, int64_t ldy, int n_out,
@@ -1171,16 +1303,27 @@ extern "C" int hnrf_mlp_dw_h(const void* dZ, int64_t ldz, const void* X, int64_t
 #define HNRF_DWH1(OT, IT, ZB_, XB_)                                                                                    \
     hipLaunchKernelGGL((mlp_dwh_kernel<OT, IT, ZB_, XB_>), dim3(pl.nsplit), dim3(256), 0, st, (const _Float16*)dZ, ldz, \
                        (const _Float16*)X, ldx, P, pl.per_wg, dz_scale, part, db ? dbpart : nullptr)
+#define HNRF_DWH_DMA(OT, IT)                                                                                         \
+    do {                                                                                                             \
+        constexpr int lds = dwh_dma_bufs(32 * 128 * OT * 2 + 32 * 32 * IT * 2) * (32 * 128 * OT * 2 + 32 * 32 * IT * 2);  \
+        static unsigned long long done = 0;                                                                          \
+        if (int rc_ = reserve_lds((const void*)mlp_dwh_dma_kernel<OT, IT>, lds, done, "hnrf_mlp_dw_h")) return rc_;   \
+        hipLaunchKernelGGL((mlp_dwh_dma_kernel<OT, IT>), dim3(pl.nsplit), dim3(256), lds, st, (const _Float16*)dZ,    \
+                           (const _Float16*)X, P, pl.per_wg, dz_scale, part, db ? dbpart : nullptr);                  \
+    } while (0)
 #define HNRF_DWH(OT, IT)                                                       \
     do {                                                                       \
-        if (zb && xb) { if (IT >= 4) HNRF_DWH1(OT, (IT >= 4 ? IT : 4), true, true); } \
+        if (zb && xb) { if (IT >= 4) { if (use_dma) HNRF_DWH_DMA(OT, (IT >= 4 ? IT : 4)); else HNRF_DWH1(OT, (IT >= 4 ? IT : 4), true, true); } } \
         else if (zb) HNRF_DWH1(OT, IT, true, false);                           \
         else HNRF_DWH1(OT, IT, false, false);                                  \
     } while (0)
+        // (HNRF_DWH_NO_DMA in the environment: the register-staged form, for A/B runs)
+        static const bool use_dma = getenv("HNRF_DWH_NO_DMA") == nullptr;
         HNRF_REQUIRE(zb || !xb, HNRF_E_UNSUPPORTED, "hnrf_mlp_dw_h: blocked X with row-major dZ is not built");
         if (n_out == 256) { if (pl.nip == 256) HNRF_DWH(2, 8); else if (pl.nip == 128) HNRF_DWH(2, 4); else HNRF_DWH(2, 2); }
         else { if (pl.nip == 256) HNRF_DWH(1, 8); else if (pl.nip == 128) HNRF_DWH(1, 4); else HNRF_DWH(1, 2); }
 #undef HNRF_DWH
+#undef HNRF_DWH_DMA
 #undef HNRF_DWH1
     }
     int rc = check_launch("hnrf_mlp_dw_h");
