@@ -139,8 +139,7 @@ __global__ void pe_bwd_kernel(const float* __restrict__ x, const float* __restri
 //   dL/dpos_b = w_b gA + dL/dw_b * grad_pos trilinear(vol_b)        (grid_sample's grid gradient)
 //   dL/dvol_b[corner] += dL/dw_b * corner weight                     (global float atomics)
 //   dL/dR_b += dL/dpos_b (x) x,   dL/dT_b += dL/dpos_b               (block reduction, 12 atomics)
-// NTH threads per block.  The LDS form (one 128-KiB grid = one block per CU) runs 4 waves per block: with 16 the
-// 8 LDS atomics per (sample, bone) pair contend and the kernel gets 10 % slower (measured 0.90 -> 1.00 ms).
+// NTH threads per block.  The LDS form (one 128-KiB grid = one block per CU) runs 16 waves per block (see the launcher).
 // lane l <- lane l + N of the same 16-lane row (0 beyond the row)
 template <int N>
 __device__ __forceinline__ int dpp_row_shl(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x100 + N, 0xF, 0xF, true); }
@@ -179,8 +178,8 @@ __global__ __launch_bounds__(NTH) void sample_warp_bwd_kernel(
 #pragma unroll
     for (int i = 0; i < 12; ++i) acc[i] = 0.f;
 
-    // The block runs one wave per SIMD (the 128-KiB grid fills the LDS), so the loop is bound by the NUMBER of
-    // instructions per (sample, bone) pair, not by latency (4 samples per trip with all loads batched: no change).
+    // One block per CU (the 128-KiB grid fills the LDS): the loop is bound by the NUMBER of instructions per (sample,
+    // bone) pair, not by latency (4 samples per trip with all loads batched: no change).
     // Hence: branch-free corners (per-axis validity folded into the corner weights, clamped addresses), three index
     // products per sample instead of one per corner, one reciprocal instead of three divisions, 32-bit sample / ray
     // arithmetic (P < 2^31 is checked by the launcher).  900 -> ~350 instructions per pair: 0.74 -> 0.44 ms with the
@@ -373,15 +372,24 @@ extern "C" int hnrf_sample_warp_bwd(const float* rays_o, const float* rays_d, co
     const size_t lds = (size_t)G * G * G * sizeof(float);
     if (lds + 256 <= 160 * 1024 && P >= 65536) {
         // one 128-KiB LDS grid per block -> 1 block per CU; ~2 waves of blocks over the chip
-        static unsigned long long lds_done = 0;
-        if (int rc = reserve_lds((const void*)sample_warp_bwd_kernel<true, 256>, 150 * 1024, lds_done, "hnrf_sample_warp_bwd"))
-            return rc;
         int64_t bx = 512 / B;                        // blocks per bone
         if (bx < 1) bx = 1;
         if (bx > blocks) bx = blocks;
-        hipLaunchKernelGGL((sample_warp_bwd_kernel<true, 256>), dim3((unsigned)bx, (unsigned)B), dim3(256), lds, st, rays_o,
-                           rays_d, z_vals, motion_Rs, motion_Ts, vol, bbox_min, bbox_scale, x_skel, fg_mask, g_x_skel,
-                           g_mask, P, S, G, d_vol, d_Rs, d_Ts);
+        // 16 waves per block (four per SIMD): with ONE wave per SIMD every one of the ~350 instructions per (sample, bone)
+        // pair costs ~5 cycles of issue (profiles/r03_mfma_issue.txt); 0.529 ms (256 threads) -> 0.357 (512) -> 0.295 (1024).
+        // (Before the atomics were folded, more waves lost to LDS-atomic contention: 0.90 -> 1.00 ms, round 2.)
+        static const int nth = getenv("HNRF_K1B_THREADS") ? atoi(getenv("HNRF_K1B_THREADS")) : 1024;
+#define HNRF_K1B(NTH_)                                                                                                   \
+    do {                                                                                                                 \
+        static unsigned long long lds_done = 0;                                                                          \
+        if (int rc = reserve_lds((const void*)sample_warp_bwd_kernel<true, NTH_>, 150 * 1024, lds_done, "hnrf_sample_warp_bwd")) \
+            return rc;                                                                                                   \
+        hipLaunchKernelGGL((sample_warp_bwd_kernel<true, NTH_>), dim3((unsigned)bx, (unsigned)B), dim3(NTH_), lds, st, rays_o, \
+                           rays_d, z_vals, motion_Rs, motion_Ts, vol, bbox_min, bbox_scale, x_skel, fg_mask, g_x_skel,  \
+                           g_mask, P, S, G, d_vol, d_Rs, d_Ts);                                                          \
+    } while (0)
+        if (nth == 512) HNRF_K1B(512); else if (nth == 1024) HNRF_K1B(1024); else HNRF_K1B(256);
+#undef HNRF_K1B
     } else {
         if (blocks > 1024) blocks = 1024;     // grid-stride: few, long blocks keep the 12-value reduction cheap
         hipLaunchKernelGGL((sample_warp_bwd_kernel<false, 256>), dim3((unsigned)blocks, (unsigned)B), dim3(256), 0, st,
