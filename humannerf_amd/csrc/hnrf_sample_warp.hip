@@ -218,8 +218,8 @@ extern "C" int hnrf_sample_warp_fwd(const float* rays_o, const float* rays_d,
     HNRF_REQUIRE(z_vals && x_skel && fg_mask, HNRF_E_ARG, "hnrf_sample_warp_fwd: null output pointer");
     HNRF_REQUIRE(R >= 0 && S >= 2 && B >= 1 && G >= 2 && G <= 1024, HNRF_E_ARG,
                  "hnrf_sample_warp_fwd: bad dims R=%lld S=%d B=%d G=%d", (long long)R, S, B, G);
-    HNRF_REQUIRE(!bmw || ((uintptr_t)bmw & 15) == 0, HNRF_E_ARG,
-                 "hnrf_sample_warp_fwd: the per-bone weight output must be 16-byte aligned (it is written in 16-byte pieces)");
+    HNRF_REQUIRE(!bmw || B != 24 || ((uintptr_t)bmw & 15) == 0, HNRF_E_ARG,
+                 "hnrf_sample_warp_fwd: with 24 bones the per-bone weight output must be 16-byte aligned (written in 16-byte pieces)");
     if (R == 0) return HNRF_OK;
     const int64_t P = R * (int64_t)S;
     const int64_t blocks = (P + 255) / 256;

@@ -81,8 +81,9 @@ size_t hnrf_nonrigid_status_offset(int mode);
  *  motion_Rs [B,3,3], motion_Ts [B,3]; vol [>=B, G,G,G] (background channel, if
  *  present, is not read); bbox_min, bbox_scale [3]   -- all device pointers.
  * Outputs: z_vals [R,S], x_skel [R,S,3], fg_mask [R,S] (= sum of weights,
- *  unclamped), bmw [R,S,B] or NULL (unnormalised per-bone weights; 16-byte
- *  aligned: it is written in 16-byte pieces, HNRF_E_ARG otherwise).
+ *  unclamped), bmw [R,S,B] or NULL (unnormalised per-bone weights; with
+ *  B == 24 16-byte aligned -- it is then written in 16-byte pieces --,
+ *  HNRF_E_ARG otherwise).
  * Every operation of the reference's tensor expressions is rounded on its own
  * (no compiler-chosen fma), so all forms of the kernel agree bit for bit. */
 int hnrf_sample_warp_fwd(const float* rays_o, const float* rays_d,
