@@ -370,7 +370,7 @@ extern "C" int hnrf_sample_warp_bwd(const float* rays_o, const float* rays_d, co
     const int64_t P = R * (int64_t)S;
     int64_t blocks = (P + 255) / 256;
     const size_t lds = (size_t)G * G * G * sizeof(float);
-    if (lds + 256 <= 160 * 1024 && P >= 65536) {
+    if (lds + 1024 <= 160 * 1024 && P >= 65536) {       // (+ the block reduction's 16 x 12 floats of static LDS)
         // one 128-KiB LDS grid per block -> 1 block per CU; ~2 waves of blocks over the chip
         int64_t bx = 512 / B;                        // blocks per bone
         if (bx < 1) bx = 1;
