@@ -239,7 +239,12 @@ __device__ __forceinline__ void dma_piece(const char* gbase, unsigned voff, unsi
 // Wave w therefore moves the CONTIGUOUS pieces [w n, (w + 1) n) of a slab (n = pieces per wave), not w, w+4, ...
 template <int R>
 __device__ __forceinline__ void dma_piece_g(const char* gbase, unsigned voff, unsigned lds_addr) {
-    asm volatile("global_load_lds_dwordx4 %0, %1 offset:%3" : : "v"(voff), "s"(gbase), "{m0}"(lds_addr), "n"(R * 1024) : "memory");
+    // a scalar write of M0 needs one wait state before an LDS-DMA instruction reads it (gfx9 hazard), and hipcc, which
+    // places the write, cannot see into the asm to insert it: hence the s_nop inside the statement.  In EVERY piece, not
+    // only a run's first: where the pieces of a run sit in different basic blocks (runtime piece counts at layer
+    // boundaries) the compiler writes M0 again in front of later pieces (the same value, so a stale read would be
+    // harmless -- but that is an argument about today's code generation, not a guarantee)
+    asm volatile("s_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 offset:%3" : : "v"(voff), "s"(gbase), "{m0}"(lds_addr), "n"(R * 1024) : "memory");
 }
 // piece i (compile-time after unrolling) of this wave's run: base addresses of the wave's run in, group of four out
 __device__ __forceinline__ void dma_run_piece(const char* run_src, unsigned voff, unsigned run_dst, int i) {
