@@ -260,18 +260,20 @@ __device__ __forceinline__ void dma_run_piece(const char* run_src, unsigned voff
 
 // DMA of nblocks 1-KiB blocks: wave w moves blocks w, w+4, ...  (nblocks % 4 == 0
 // wherever a counted wait follows, so that every wave has the same count in flight)
-__device__ __forceinline__ void slab_issue(const char* gsrc, unsigned lds_addr, int nblocks, int wave) {
+__device__ __forceinline__ void slab_issue(const char* gsrc, unsigned lds_addr, int nblocks, int wave, int nw = 4) {
     const unsigned voff = lane_now() * 16;
-    for (int b = wave; b < nblocks; b += 4) dma_piece(gsrc + b * 1024, voff, lds_addr + b * 1024);
+    for (int b = wave; b < nblocks; b += nw) dma_piece(gsrc + b * 1024, voff, lds_addr + b * 1024);
 }
 
 // wait until at most `keep` of this wave's DMA pieces are still in flight
 __device__ __forceinline__ void wait_dma_keep(int keep) {
 #define HNRF_VMCNT_CASE(N) case N: asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory"); break;
     switch (keep) {
-        HNRF_VMCNT_CASE(4) HNRF_VMCNT_CASE(6) HNRF_VMCNT_CASE(8) HNRF_VMCNT_CASE(10)
-        // training variant: the 4 activation stores per finished tile sit in the same in-order queue
-        HNRF_VMCNT_CASE(12) HNRF_VMCNT_CASE(14) HNRF_VMCNT_CASE(16) HNRF_VMCNT_CASE(18) HNRF_VMCNT_CASE(20)
+        // (even counts: four waves per workgroup; the odd ones: eight, 2 or 3 pieces per wave and slab.  Training variants:
+        // the 4 activation stores per finished tile sit in the same in-order queue)
+        HNRF_VMCNT_CASE(1) HNRF_VMCNT_CASE(2) HNRF_VMCNT_CASE(3) HNRF_VMCNT_CASE(4) HNRF_VMCNT_CASE(5) HNRF_VMCNT_CASE(6)
+        HNRF_VMCNT_CASE(7) HNRF_VMCNT_CASE(8) HNRF_VMCNT_CASE(9) HNRF_VMCNT_CASE(10) HNRF_VMCNT_CASE(11) HNRF_VMCNT_CASE(12)
+        HNRF_VMCNT_CASE(13) HNRF_VMCNT_CASE(14) HNRF_VMCNT_CASE(15) HNRF_VMCNT_CASE(16) HNRF_VMCNT_CASE(18) HNRF_VMCNT_CASE(20)
         HNRF_VMCNT_CASE(22) HNRF_VMCNT_CASE(24) HNRF_VMCNT_CASE(26) HNRF_VMCNT_CASE(28) HNRF_VMCNT_CASE(30)
         HNRF_VMCNT_CASE(32) HNRF_VMCNT_CASE(34) HNRF_VMCNT_CASE(36) HNRF_VMCNT_CASE(38) HNRF_VMCNT_CASE(40)
         default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
@@ -591,7 +593,7 @@ __device__ __forceinline__ h16x2 epi_pair_mh(const f32x16& a1, const f32x16& a2,
 //     behind; with DEFER it is left pending in (pend1, pend2) and the next layer (PEND_IN) runs it inside its first
 //     tile, writing the last two fragments of its own input just before the k-steps that consume them.
 template <int NT, int TPS, int NKA, int NKB, bool RELU, int SAVE = 0, bool PEND_IN = false, bool DEFER = false,
-          bool ULO = false, int NB, int NO>
+          bool ULO = false, int NW = 4, int NB, int NO>
 __device__ __forceinline__ void layer16(Pipe& p, int nb1, int nb2, h16x8 (&bh)[NB], h16x8 (&bl)[NB],
                                         h16x8 (&oh)[NO], h16x8 (&ol)[NO], float (&last)[16], SaveCtx* sc = nullptr,
                                         f32x16* pend1 = nullptr, f32x16* pend2 = nullptr) {
@@ -602,7 +604,7 @@ __device__ __forceinline__ void layer16(Pipe& p, int nb1, int nb2, h16x8 (&bh)[N
     constexpr int NBLK = 2 * NK;             // blocks per tile
     constexpr int NS = NT / TPS;             // slabs of this layer
     constexpr int PFK = NK < 4 ? NK : 4;
-    static_assert((NBLK * TPS) % 4 == 0, "every wave must issue the same number of DMA pieces per slab");
+    static_assert((NBLK * TPS) % NW == 0, "every wave must issue the same number of DMA pieces per slab");
     static_assert(!ULO || SAVE == SV_NONE || sv_fwd(SAVE), "un-scaled activation low parts exist in the forward kernels only");
     f32x16 pacc1 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     f32x16 pacc2 = pacc1;                    // accumulators of the previous tile (epilogue pending)
@@ -624,7 +626,7 @@ __device__ __forceinline__ void layer16(Pipe& p, int nb1, int nb2, h16x8 (&bh)[N
         // its 1-KiB pieces are issued one per k-step INSIDE this slab's MFMA stream (an LDS-DMA issue
         // costs ~100-150 cycles of the wave's issue slot: 8-10 of them in front of the tile idle the
         // matrix pipe for ~1000 cycles per tile -- measured with cycle stamps)
-        const int dcnt = nissue / 4;                       // pieces per wave: this wave moves the run [wave dcnt, (wave + 1) dcnt)
+        const int dcnt = nissue / NW;                      // pieces per wave: this wave moves the run [wave dcnt, (wave + 1) dcnt)
         const char* dsrc = p.gi + p.wave * dcnt * 1024;
         const unsigned ddst = p.lds_base + p.ring_off + slot2 * p.slab_bytes + p.wave * dcnt * 1024;
         p.gi += nissue * 1024;
@@ -704,7 +706,7 @@ __device__ __forceinline__ void layer16(Pipe& p, int nb1, int nb2, h16x8 (&bh)[N
                     const int i = tt * NK + ks;
                     if (i >= 0 && i < MAXP) {
                         if (s + 2 < NS) {                      // piece count known at compile time
-                            if (i < NBLK * TPS / 4) dma_run_piece(dsrc, lane * 16, ddst, i);
+                            if (i < NBLK * TPS / NW) dma_run_piece(dsrc, lane * 16, ddst, i);
                         } else if (i < dcnt) {                 // wave-uniform branch (layer-boundary slabs)
                             dma_run_piece(dsrc, lane * 16, ddst, i);
                         }
@@ -775,7 +777,7 @@ __device__ __forceinline__ void layer16(Pipe& p, int nb1, int nb2, h16x8 (&bh)[N
         // SAVE: the activation stores issued during this slab (4 per tile that had a pending epilogue) are younger
         // than every piece of slab n+1 as well, so they may stay in flight too
         const int n_st = (sv_fwd(SAVE) || sv_bwd(SAVE)) ? 4 * (s == 0 ? TPS - 1 : TPS) : 0;
-        tile_sync(nissue / 4 + n_st);
+        tile_sync(nissue / NW + n_st);
         p.ph = p.ph == RING - 1 ? 0 : p.ph + 1;
         p.bias_off += TPS * 128;
     }
@@ -968,7 +970,7 @@ __device__ __forceinline__ void layer16x2(Pipe& p, unsigned stash_per_wave, int 
 
 // Starts the pipeline: bias table + the first two slabs are put in flight.
 __device__ __forceinline__ Pipe pipe_start(const char* packed, int64_t bias_img_off, int bias_bytes, int slab_bytes,
-                                           int nb0, int nb1, char* smem, int stash_bytes = PE_STASH) {
+                                           int nb0, int nb1, char* smem, int stash_bytes = PE_STASH, int nw = 4) {
     Pipe p;
     p.wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     p.lds_base = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lds_char*)smem);
@@ -983,9 +985,9 @@ __device__ __forceinline__ Pipe pipe_start(const char* packed, int64_t bias_img_
     p.t_last = __builtin_readcyclecounter();
     p.sum_k = p.sum_b = 0;
 #endif
-    slab_issue(packed + bias_img_off, p.lds_base, bias_bytes / 1024, p.wave);
-    slab_issue(packed, p.lds_base + p.ring_off, nb0, p.wave);
-    slab_issue(packed + nb0 * 1024, p.lds_base + p.ring_off + slab_bytes, nb1, p.wave);
+    slab_issue(packed + bias_img_off, p.lds_base, bias_bytes / 1024, p.wave, nw);
+    slab_issue(packed, p.lds_base + p.ring_off, nb0, p.wave, nw);
+    slab_issue(packed + nb0 * 1024, p.lds_base + p.ring_off + slab_bytes, nb1, p.wave, nw);
     p.gi = packed + (nb0 + nb1) * 1024;
     return p;
 }
@@ -1101,8 +1103,16 @@ __global__ __launch_bounds__(256) void canonical_f16x3_kernel(const float* __res
 
 // K2, f16x3 (width 128: 4 tiles, 8 k-steps).  SAVE: pe_out [P,36], acts [6][P][128], relu_bits [6][P][4];
 // SV_ACT_H: f16 acts and an f16 pe_out [P][64] (columns 36..63 zero).
-template <int SAVE>
-__global__ __launch_bounds__(256) void nonrigid_f16x3_kernel(const float* __restrict__ x_skel,
+// NW = 8 (training forward, P a multiple of 256): EIGHT waves share the weight ring -- two per SIMD.  With one wave per
+// SIMD every instruction of this issue-bound kernel (6.5 other instructions per MFMA) costs ~5 cycles next to the MFMAs'
+// 32 (profiles/r03_mfma_issue.txt); a second wave fills those slots.  The registers allow it (239 VGPRs, no AGPRs); the
+// LDS does with the two-group kernel's layout: 3 KiB bias + 8 x 8 KiB PE stash + 3 x 24 KiB slabs = 139 KiB, one tile per
+// slab except layer 0's two.  Same image, same per-wave arithmetic and store addresses: bit-identical results.
+constexpr int NR16W8_SLAB = 24 * 1024;
+constexpr int NR16W8_STASH = 64 * 1024;
+
+template <int SAVE, int NW = 4>
+__global__ __launch_bounds__(64 * NW) void nonrigid_f16x3_kernel(const float* __restrict__ x_skel,
                                                              const float* __restrict__ hann_w,
                                                              const char* __restrict__ packed, int64_t P,
                                                              float* __restrict__ xyz, float* __restrict__ offsets,
@@ -1114,11 +1124,14 @@ __global__ __launch_bounds__(256) void nonrigid_f16x3_kernel(const float* __rest
     extern __shared__ __attribute__((aligned(16))) char smem[];
     if (idx != nullptr) {
         P = *count;
-        if ((int64_t)blockIdx.x * 128 >= P) return;
+        if ((int64_t)blockIdx.x * (32 * NW) >= P) return;
     }
-    Pipe p = pipe_start(packed, NR16_BIAS, NR16_BIAS_LDS, NR16_SLAB, 4 * NR16_NB_L0, 2 * NR16_NB_MID, smem);
+    static_assert(NW == 4 || NW == 8, "waves per workgroup");
+    constexpr bool W8 = NW == 8;
+    Pipe p = W8 ? pipe_start(packed, NR16_BIAS, NR16_BIAS_LDS, NR16W8_SLAB, 2 * NR16_NB_L0, 2 * NR16_NB_L0, smem, NR16W8_STASH, 8)
+                : pipe_start(packed, NR16_BIAS, NR16_BIAS_LDS, NR16_SLAB, 4 * NR16_NB_L0, 2 * NR16_NB_MID, smem);
     const int lane = threadIdx.x & 63, h = lane >> 5;
-    const int64_t slot = ((int64_t)blockIdx.x * 4 + p.wave) * 32 + (lane & 31);
+    const int64_t slot = ((int64_t)blockIdx.x * NW + p.wave) * 32 + (lane & 31);
     const int64_t sclamp = slot < P ? slot : P - 1;
     const int64_t sidx = idx ? (int64_t)idx[sclamp] : sclamp;
     const int64_t sample = slot < P ? sidx : P;
@@ -1154,11 +1167,29 @@ __global__ __launch_bounds__(256) void nonrigid_f16x3_kernel(const float* __rest
         }
     }
     const int64_t act_stride = P * 128, bit_stride = P * 4;
-    const int64_t acth_stride = (int64_t)gridDim.x * 128 * 128;
+    const int64_t acth_stride = (int64_t)gridDim.x * (32 * NW) * 128;       // blocked f16 layers are padded to whole workgroups
     tile_sync(0);
 
     h16x8 hA_h[8], hA_l[8], hB_h[8], hB_l[8];
     float last[16];
+    h16x8 dh[2], dl[2];
+    if constexpr (W8) {
+        constexpr int MID = NR16_NB_MID, L4B = NR16_NB_L4;      // blocks per tile: 16 / 24
+#define HNRF_NEXT_LAYER if constexpr (SAVE) { sc.row += act_stride; sc.rowh += acth_stride; sc.bits += bit_stride; }
+        layer16<4, 2, 4, 0, true, SAVE, false, false, UL, 8>(p, MID, MID, hB_h, hB_l, hA_h, hA_l, last, &sc);        // L0
+        HNRF_NEXT_LAYER
+        layer16<4, 1, 0, 8, true, SAVE, false, false, UL, 8>(p, MID, MID, hA_h, hA_l, hB_h, hB_l, last, &sc);        // L1
+        HNRF_NEXT_LAYER
+        layer16<4, 1, 0, 8, true, SAVE, false, false, UL, 8>(p, MID, MID, hB_h, hB_l, hA_h, hA_l, last, &sc);        // L2
+        HNRF_NEXT_LAYER
+        layer16<4, 1, 0, 8, true, SAVE, false, false, UL, 8>(p, L4B, L4B, hA_h, hA_l, hB_h, hB_l, last, &sc);        // L3
+        HNRF_NEXT_LAYER
+        layer16<4, 1, 4, 8, true, SAVE, false, false, UL, 8>(p, MID, MID, hB_h, hB_l, hA_h, hA_l, last, &sc);        // skip layer
+        HNRF_NEXT_LAYER
+        layer16<4, 1, 0, 8, true, SAVE, false, false, UL, 8>(p, MID, 0, hA_h, hA_l, hB_h, hB_l, last, &sc);
+#undef HNRF_NEXT_LAYER
+        layer16<1, 1, 0, 8, false, 0, false, false, UL, 8>(p, 0, 0, hB_h, hB_l, dh, dl, last);
+    } else {
     layer16<4, 4, 4, 0, true, SAVE, false, false, UL>(p, 0 /*already in flight*/, 2 * NR16_NB_MID, hB_h, hB_l, hA_h, hA_l, last, &sc);
     if constexpr (SAVE) { sc.row += act_stride; sc.rowh += acth_stride; sc.bits += bit_stride; }
     // 128-wide tiles have only 8 k-steps: two tiles per slab halve the barriers per MFMA.  The layers alternate
@@ -1172,8 +1203,8 @@ __global__ __launch_bounds__(256) void nonrigid_f16x3_kernel(const float* __rest
     layer16<4, 1, 4, 8, true, SAVE, false, false, UL>(p, 2 * NR16_NB_MID, 2 * NR16_NB_MID, hB_h, hB_l, hA_h, hA_l, last, &sc);    // skip layer
     if constexpr (SAVE) { sc.row += act_stride; sc.rowh += acth_stride; sc.bits += bit_stride; }
     layer16<4, 2, 0, 8, true, SAVE, false, false, UL>(p, NR16_NB_MID, 0, hA_h, hA_l, hB_h, hB_l, last, &sc);
-    h16x8 dh[2], dl[2];
     layer16<1, 1, 0, 8, false, 0, false, false, UL>(p, 0, 0, hB_h, hB_l, dh, dl, last);
+    }
     const float* ob = reinterpret_cast<const float*>(packed + NR16_BIAS + NR16_BIAS_LDS);
     const float hs = ob[8];                                     // head descale (pack_layer16_kernel, head_scale)
     if (h == 0 && slot < P) {
@@ -1742,7 +1773,17 @@ int nonrigid16_fwd_train(const float* x_skel, const float* hann_w, const void* p
     constexpr int lds = NR16_BIAS_LDS + PE_STASH + RING * NR16_SLAB;
     static unsigned long long lds_done = 0, lds_done_h = 0;
     const dim3 grid((unsigned)((P + 127) / 128));
-    if (half) {
+    // eight waves per workgroup where the sample count allows it (whole 256-sample workgroups: the blocked activation
+    // layers are padded to whole workgroups, and the chain / weight-gradient kernels pad to 128); HNRF_K2T_W4: the
+    // four-wave form, for A/B runs
+    static const bool w8_ok = getenv("HNRF_K2T_W4") == nullptr;
+    if (half && w8_ok && P % 256 == 0) {
+        constexpr int lds8 = NR16_BIAS_LDS + NR16W8_STASH + RING * NR16W8_SLAB;
+        static unsigned long long lds_done_8 = 0;
+        if (int rc = reserve_lds((const void*)nonrigid_f16x3_kernel<SV_ACT_H, 8>, lds8, lds_done_8, "hnrf_nonrigid_fwd_train (f16x3, f16 operands, 8 waves)")) return rc;
+        hipLaunchKernelGGL((nonrigid_f16x3_kernel<SV_ACT_H, 8>), dim3((unsigned)(P / 256)), dim3(512), lds8, st, x_skel, hann_w,
+                           (const char*)packed, P, xyz, offsets, nullptr, nullptr, pe_out, acts, relu_bits);
+    } else if (half) {
         if (int rc = reserve_lds((const void*)nonrigid_f16x3_kernel<SV_ACT_H>, lds, lds_done_h, "hnrf_nonrigid_fwd_train (f16x3, f16 operands)")) return rc;
         hipLaunchKernelGGL(nonrigid_f16x3_kernel<SV_ACT_H>, grid, dim3(256), lds, st, x_skel, hann_w, (const char*)packed, P,
                            xyz, offsets, nullptr, nullptr, pe_out, acts, relu_bits);
