@@ -1547,8 +1547,9 @@ constexpr int64_t NB16_BYTES = NB16_L0P + NB16_PE;            // followed by flo
 
 // Non-rigid MLP, split-f16 (xyz = x_skel + offset): d_x_skel = d_xyz + J_offset^T d_xyz, dZ [6][P][128].
 // HALF: see canonical_bwd16_kernel.
-template <bool HALF>
-__global__ __launch_bounds__(256) void nonrigid_bwd16_kernel(const float* __restrict__ x_skel,
+// NW = 8: eight waves per workgroup as in nonrigid_f16x3_kernel (one tile per slab, 16-KiB ring slots; P a multiple of 256)
+template <bool HALF, int NW = 4>
+__global__ __launch_bounds__(64 * NW) void nonrigid_bwd16_kernel(const float* __restrict__ x_skel,
                                                              const float* __restrict__ hann_w,
                                                              const float* __restrict__ d_xyz,
                                                              const uint32_t* __restrict__ relu_bits,
@@ -1558,11 +1559,14 @@ __global__ __launch_bounds__(256) void nonrigid_bwd16_kernel(const float* __rest
                                                              float* __restrict__ dz_amax) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int SV = HALF ? SV_DZ_H : SV_DZ;
-    Pipe p = pipe_start(packed, 0, NR16_BIAS_LDS, NR16_SLAB, 8, 32, smem);
-    slab_issue(p.gi, p.lds_base + p.ring_off + 2 * NR16_SLAB, 32, p.wave);      // third slab: see canonical_bwd16_kernel
-    p.gi += 32 * 1024;
+    constexpr bool W8 = NW == 8;
+    constexpr int SLAB = W8 ? 16 * 1024 : NR16_SLAB, SB = W8 ? 16 : 32;         // ring slot bytes; blocks per mid-layer slab
+    constexpr int TP = W8 ? 1 : 2;                                               // tiles per slab of the 128-wide stages
+    Pipe p = pipe_start(packed, 0, NR16_BIAS_LDS, SLAB, 8, SB, smem, W8 ? NR16W8_STASH : PE_STASH, NW);
+    slab_issue(p.gi, p.lds_base + p.ring_off + 2 * SLAB, SB, p.wave, NW);       // third slab: see canonical_bwd16_kernel
+    p.gi += SB * 1024;
     const int lane = threadIdx.x & 63, h = lane >> 5;
-    const int64_t slot = ((int64_t)blockIdx.x * 4 + p.wave) * 32 + (lane & 31);
+    const int64_t slot = ((int64_t)blockIdx.x * NW + p.wave) * 32 + (lane & 31);
     const int64_t sample = slot < P ? slot : P - 1;
     const int64_t stride = P * 128, bstride = P * 4;
     const float* wmax = reinterpret_cast<const float*>(packed + NB16_BYTES);
@@ -1584,7 +1588,7 @@ __global__ __launch_bounds__(256) void nonrigid_bwd16_kernel(const float* __rest
     sc.amax = 0.f;
     sc.mask[2] = sc.mask[3] = 0u;
     sc.row = dZ + 5 * stride + sample * 128 + 4 * h;
-    const int64_t strideh = (int64_t)gridDim.x * 128 * 128;
+    const int64_t strideh = (int64_t)gridDim.x * (32 * NW) * 128;
     sc.rowh = reinterpret_cast<_Float16*>(dZ) + 5 * strideh + (slot >> 5) * (128 * 32) + h * 128;
     sc.cx = (lane & 31) ^ (4 * h);
     const uint32_t* mrow = relu_bits + 5 * bstride + sample * 4 + 2 * h;
@@ -1611,29 +1615,29 @@ __global__ __launch_bounds__(256) void nonrigid_bwd16_kernel(const float* __rest
     h16x8 dh[4], dl[4];
     float last[16];
     load_mask();
-    layer16<4, 4, 1, 0, false, SV>(p, 0, 0, hB_h, hB_l, hA_h, hA_l, last, &sc);                // dZ5
+    layer16<4, 4, 1, 0, false, SV, false, false, false, NW>(p, 0, 0, hB_h, hB_l, hA_h, hA_l, last, &sc);   // dZ5
     next_stage(5);
     load_mask();
-    layer16<4, 2, 0, 8, false, SV>(p, 32, 32, hA_h, hA_l, hB_h, hB_l, last, &sc);             // dZ4 (the skip layer's)
+    layer16<4, TP, 0, 8, false, SV, false, false, false, NW>(p, SB, SB, hA_h, hA_l, hB_h, hB_l, last, &sc);             // dZ4 (the skip layer's)
     next_stage(4);
     load_mask();
-    layer16<4, 2, 0, 8, false, SV>(p, 32, 32, hB_h, hB_l, hA_h, hA_l, last, &sc);             // skip [h | PE]: dZ3 ...
+    layer16<4, TP, 0, 8, false, SV, false, false, false, NW>(p, SB, SB, hB_h, hB_l, hA_h, hA_l, last, &sc);             // skip [h | PE]: dZ3 ...
     const float inv_skip = sc.descale;                                                         // (W4^T: hidden and PE rows share kt[4])
     next_stage(3);
-    layer16<2, 2, 0, 8, false, SV_PE>(p, 32, 32, hB_h, hB_l, dh, dl, last, &sc);              // ... and its d PE
+    layer16<2, TP, 0, 8, false, SV_PE, false, false, false, NW>(p, SB, SB, hB_h, hB_l, dh, dl, last, &sc);              // ... and its d PE
     float dpe[18];
 #pragma unroll
     for (int j = 0; j < 18; ++j) dpe[j] = sc.fout[j] * inv_skip;
     load_mask();
-    layer16<4, 2, 0, 8, false, SV>(p, 32, 32, hA_h, hA_l, hB_h, hB_l, last, &sc);             // dZ2
+    layer16<4, TP, 0, 8, false, SV, false, false, false, NW>(p, SB, SB, hA_h, hA_l, hB_h, hB_l, last, &sc);             // dZ2
     next_stage(2);
     load_mask();
-    layer16<4, 2, 0, 8, false, SV>(p, 32, 32, hB_h, hB_l, hA_h, hA_l, last, &sc);             // dZ1
+    layer16<4, TP, 0, 8, false, SV, false, false, false, NW>(p, SB, SB, hB_h, hB_l, hA_h, hA_l, last, &sc);             // dZ1
     next_stage(1);
     load_mask();
-    layer16<4, 2, 0, 8, false, SV>(p, 32, 0, hA_h, hA_l, hB_h, hB_l, last, &sc);              // dZ0
+    layer16<4, TP, 0, 8, false, SV, false, false, false, NW>(p, SB, W8 ? SB : 0, hA_h, hA_l, hB_h, hB_l, last, &sc);   // dZ0
     next_stage(0);                                                                             // (scale of layer 0's d PE)
-    layer16<2, 2, 0, 8, false, SV_PE>(p, 0, 0, hB_h, hB_l, dh, dl, last, &sc);                // layer 0's d PE
+    layer16<2, TP, 0, 8, false, SV_PE, false, false, false, NW>(p, 0, 0, hB_h, hB_l, dh, dl, last, &sc);   // layer 0's d PE
 #pragma unroll
     for (int j = 0; j < 18; ++j) dpe[j] = fmaf(sc.fout[j], sc.descale, dpe[j]);
 
@@ -1880,6 +1884,8 @@ int nonrigid16_bwd(const float* x_skel, const float* hann_w, const float* d_xyz,
     constexpr int lds = NR16_BIAS_LDS + PE_STASH + RING * NR16_SLAB;
     static unsigned long long lds_done = 0, lds_done_h = 0;
     const dim3 grid((unsigned)((P + 127) / 128));
+    // (an eight-wave instance as in nonrigid16_fwd_train -- nonrigid_bwd16_kernel<true, 8> -- was built and measured: the chain
+    // needs 292 registers per lane, at 256 it spills 260 bytes and runs 0.659 instead of 0.605 ms; not dispatched)
     if (half) {
         if (int rc = reserve_lds((const void*)nonrigid_bwd16_kernel<true>, lds, lds_done_h, "hnrf_nonrigid_bwd (f16x3, f16 operands)")) return rc;
         hipLaunchKernelGGL(nonrigid_bwd16_kernel<true>, grid, dim3(256), lds, st, x_skel, hann_w, d_xyz, relu_bits,
